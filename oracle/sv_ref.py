@@ -1,0 +1,341 @@
+"""ORACLE — functional CPU restatement of the SVNet hot path (test infrastructure only).
+
+State lives in a plain {name: tensor} dict that uses the reference's state_dict names
+(SURVEY.md Appendix D), so one set of weights can be loaded into the reference, into this
+oracle and into the HIP product.  `Ctx` carries train/eval mode, the k-NN backend and, in
+train mode, collects the BatchNorm running-statistic updates the reference applies in place.
+
+Reference files restated (all under /root/reference/models/):
+  utils/sv_util.py:19-144   knn, get_graph_feature[_cross|_sv], svpool, svcat
+  sv_layers.py:20-244       Linear, Conv1d, VectorBN, Vector2Scalar, VectorReLU, SVBlock, SVFuse, SV_STNkd
+  sv_dgcnn_cls.py:22-82, sv_pointnet_cls.py:12-81, sv_dgcnn_partseg.py:40-128   the three callers
+  ../utils.py:33-50         cal_loss
+"""
+import torch
+import torch.nn.functional as F
+
+from . import knn as _knn
+
+EPS = 1e-6           # sv_layers.py:18
+BN_EPS = 1e-5        # nn.BatchNorm1d default
+BN_MOMENTUM = 0.1    # nn.BatchNorm1d default
+STE_CLIP = 1.2       # sv_layers.py:41,47
+
+
+class Ctx:
+    def __init__(self, train=False, knn="exact", collect_bn=False):
+        self.train = train
+        self.knn = knn                      # "exact" (C fmaf chain) | "torch" (reference op chain)
+        self.bn_updates = {} if collect_bn else None
+        self.taps = None                    # optional {name: tensor} of intermediate results
+
+
+# ----------------------------------------------------------------------------- graph utilities
+
+def knn_indices(x, k, ctx=None):
+    """sv_util.py:19-25. x: [B,C,N] (any strides). -> [B,N,k] int64, nearest first."""
+    if ctx is not None and ctx.knn == "torch":
+        return _knn.knn_torch(x.detach(), k)
+    return _knn.knn_exact(x.detach(), k)
+
+
+def _neighbour_rows(flat_rows, idx, B, N, k):
+    """Gather rows of a [B*N, F] table for cloud-local idx [B,N,k] (sv_util.py:40-51)."""
+    glob = idx + (torch.arange(B).view(B, 1, 1) * N)
+    return flat_rows[glob.reshape(-1)].view(B, N, k, -1)
+
+
+def graph_feature(x, k=20, idx=None, x_coord=None, first=False, ctx=None):
+    """sv_util.py:28-62 (get_graph_feature). x: [B,1,3m,N] -> [B,N,k,3,2m]."""
+    B, N = x.size(0), x.size(3)
+    pts = x.reshape(B, -1, N)
+    if idx is None:
+        src = pts if x_coord is None else x_coord.reshape(B, -1, N)
+        idx = knn_indices(src, k, ctx)
+    m = pts.size(1) // 3
+    rows = pts.transpose(2, 1).contiguous()                       # [B,N,3m], channel = m*3+d
+    nbr = _neighbour_rows(rows.view(B * N, -1), idx, B, N, k).view(B, N, k, m, 3)
+    ctr = rows.view(B, N, 1, m, 3).expand(B, N, k, m, 3)
+    rel = nbr - ctr
+    second = rel.mean(dim=2, keepdim=True).expand_as(rel) if first else ctr
+    return torch.cat((rel, second), dim=3).transpose(-1, -2).contiguous()   # [B,N,k,3,2m]
+
+
+def graph_feature_cross(x, k=20, idx=None, ctx=None):
+    """sv_util.py:64-88 (get_graph_feature_cross). -> [B,N,k,3,3m]: (x_j-x_i, x_i, x_j x x_i)."""
+    B, N = x.size(0), x.size(3)
+    pts = x.reshape(B, -1, N)
+    if idx is None:
+        idx = knn_indices(pts, k, ctx)
+    m = pts.size(1) // 3
+    rows = pts.transpose(2, 1).contiguous()
+    nbr = _neighbour_rows(rows.view(B * N, -1), idx, B, N, k).view(B, N, k, m, 3)
+    ctr = rows.view(B, N, 1, m, 3).expand(B, N, k, m, 3)
+    a, b = nbr, ctr
+    crs = torch.stack((a[..., 1] * b[..., 2] - a[..., 2] * b[..., 1],
+                       a[..., 2] * b[..., 0] - a[..., 0] * b[..., 2],
+                       a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]), dim=-1)
+    return torch.cat((nbr - ctr, ctr, crs), dim=3).transpose(-1, -2).contiguous()
+
+
+def graph_feature_sv(x, k=20, idx=None, ctx=None):
+    """sv_util.py:90-116 (get_graph_feature_sv). s:[B,N,Cs], v:[B,N,3,Cv] ->
+    s_e [B,N,k,2Cs] = [s_j-s_i, s_i],  v_e [B,N,k,3,2Cv] = [v_j-v_i, v_i].
+    A caller-supplied idx is taken as GLOBAL row ids (B*N*k of them), as the reference does (:99-111)."""
+    s, v = x
+    B, N, Cs = s.shape
+    Cv = v.size(-1)
+    if idx is None:
+        feat = torch.cat([s, v.reshape(B, N, -1)], dim=-1)       # channel order: s, then v row-major (3,Cv)
+        loc = knn_indices(feat.transpose(-1, -2), k, ctx)
+        glob = (loc + torch.arange(B).view(B, 1, 1) * N).reshape(-1)
+    else:
+        glob = idx.reshape(-1)
+    v_j = v.reshape(B * N, -1)[glob].view(B, N, k, 3, Cv)
+    v_i = v.view(B, N, 1, 3, Cv).expand(B, N, k, 3, Cv)
+    s_j = s.reshape(B * N, -1)[glob].view(B, N, k, Cs)
+    s_i = s.view(B, N, 1, Cs).expand(B, N, k, Cs)
+    return torch.cat((s_j - s_i, s_i), dim=-1), torch.cat((v_j - v_i, v_i), dim=-1)
+
+
+def svpool(x, dim=2, keepdim=False, spool="max"):
+    """sv_util.py:118-132. s: max (or mean) over `dim`; v: mean over `dim`."""
+    s, v = x
+    if spool == "max":
+        s = s.max(dim=dim, keepdim=keepdim)[0]
+    elif spool == "mean":
+        s = s.mean(dim=dim, keepdim=keepdim)
+    else:
+        raise ValueError("not recognized pooling mean {}".format(spool))
+    return s, v.mean(dim=dim, keepdim=keepdim)
+
+
+def svcat(xs):
+    """sv_util.py:134-144."""
+    return torch.cat([a for a, _ in xs], dim=-1), torch.cat([b for _, b in xs], dim=-1)
+
+
+# ----------------------------------------------------------------------------- layers
+
+def binarize(t, train):
+    """sv_layers.py:38-42 / :44-48. eval: sign (sign(0)=0 -> ternary). train: clamp + STE, evaluated
+    in the reference's fp32 order ((sign + t) - t), identity gradient where |t| <= 1.2."""
+    if not train:
+        return torch.sign(t)
+    tc = torch.clamp(t, -STE_CLIP, STE_CLIP)
+    return torch.sign(tc).detach() + tc - tc.detach()
+
+
+def linear(x, P, name, bw=False, ba=False, ctx=None):
+    """sv_layers.py:20-53 (Linear). Params: name.weight [O,K], name.bias?, name.beta [1,K] (ba), name.scale [1,O] (bw)."""
+    W = P[name + ".weight"]
+    bias = P.get(name + ".bias")
+    if not bw and not ba:
+        return F.linear(x, W, bias)
+    if ba and not bw:
+        raise AttributeError("Linear(ba=True, bw=False) has no scale (sv_layers.py:49)")
+    train = bool(ctx and ctx.train)
+    rows = x.reshape(-1, x.shape[-1])
+    if ba:
+        rows = binarize(rows + P[name + ".beta"], train)
+    y = (rows @ binarize(W, train).t()) * P[name + ".scale"]
+    if bias is not None:
+        y = y + bias
+    return y.view(x.shape[:-1] + (y.shape[-1],))
+
+
+def conv1d(x, P, name, binary=False, ctx=None):
+    """sv_layers.py:55-78 (Conv1d, kernel 1, no bias). x: [B,C,N]; name.weight [O,C,1], beta [1,C,1], scale [1,O,1]."""
+    W = P[name + ".weight"]
+    if not binary:
+        return torch.einsum("oc,bcn->bon", W[:, :, 0], x)
+    train = bool(ctx and ctx.train)
+    xb = binarize(x + P[name + ".beta"], train)
+    wb = binarize(W, train)
+    return torch.einsum("oc,bcn->bon", wb[:, :, 0], xb) * P[name + ".scale"]
+
+
+def batch_norm(x2d, P, name, ctx=None):
+    """nn.BatchNorm1d over rows of [M,C] (sv_layers.py:84,166,189): train = batch statistics
+    (biased variance), eval = running statistics."""
+    w, b = P[name + ".weight"], P[name + ".bias"]
+    if ctx is not None and ctx.train:
+        if ctx.bn_updates is not None:
+            with torch.no_grad():
+                M = x2d.shape[0]
+                mean = x2d.mean(dim=0)
+                unb = x2d.var(dim=0, unbiased=False) * (M / max(M - 1, 1))
+                rm, rv = P[name + ".running_mean"], P[name + ".running_var"]
+                ctx.bn_updates[name + ".running_mean"] = (1 - BN_MOMENTUM) * rm + BN_MOMENTUM * mean
+                ctx.bn_updates[name + ".running_var"] = (1 - BN_MOMENTUM) * rv + BN_MOMENTUM * unb
+        # y = (x - mean_batch) / sqrt(var_batch_biased + eps) * w + b, evaluated by the same ATen
+        # primitive the reference's nn.BatchNorm1d calls, so that train-mode parity with the reference
+        # is not limited by the summation order of the batch statistics (binary nets amplify 1e-6
+        # differences into sign flips one layer later).
+        return F.batch_norm(x2d, None, None, w, b, True, 0.0, BN_EPS)
+    mean, var = P[name + ".running_mean"], P[name + ".running_var"]
+    return F.batch_norm(x2d, mean, var, w, b, False, 0.0, BN_EPS)
+
+
+def batch_norm_cf(x, P, name, ctx=None):
+    """nn.BatchNorm1d on channel-first [B,C,N] (part-seg head, sv_dgcnn_partseg.py:60-77)."""
+    B, C, N = x.shape
+    y = batch_norm(x.transpose(1, 2).reshape(-1, C), P, name, ctx)
+    return y.view(B, N, C).transpose(1, 2)
+
+
+def vector_bn(v, P, name, ctx=None):
+    """sv_layers.py:81-102 (VectorBN). v: [...,3,C]. n = |v|_2 over the 3-axis + EPS; v * BN(n) / n."""
+    C = v.shape[-1]
+    n = torch.linalg.vector_norm(v, dim=-2) + EPS
+    n_bn = batch_norm(n.reshape(-1, C), P, name + ".bn", ctx).view(n.shape)
+    return v / n.unsqueeze(-2) * n_bn.unsqueeze(-2)
+
+
+def vector2scalar(v, P, name, binary=False, trans_back=False, ctx=None):
+    """sv_layers.py:104-129 (Vector2Scalar). z = Linear(v) [...,3,multi]; s[d*multi+j] = sum_i v[i,d] z[i,j]."""
+    assert v.dim() in (3, 4, 5), "dim of v should be in [4, 5], got {}".format(v.dim())
+    z = linear(v, P, name + ".linear", bw=binary, ctx=ctx)
+    s = torch.matmul(v.transpose(-1, -2), z)                     # [...,C,multi]
+    s = s.reshape(z.shape[:-2] + (-1,))
+    return (s, z) if trans_back else s
+
+
+def vector_relu(x, div=10):
+    """sv_layers.py:131-149 (VectorReLU; never instantiated by any model)."""
+    shape = x.shape
+    B, C = shape[0], shape[-1]
+    rows = x.reshape(B, -1, 3, C)
+    kth = rows.shape[1] // div
+    nrm = torch.sqrt((rows * rows).sum(dim=2, keepdim=True)).detach()
+    thr = torch.kthvalue(nrm, kth, dim=1, keepdim=True)[0]
+    return torch.where(nrm > thr, rows, torch.zeros_like(rows)).view(shape)
+
+
+def svblock(x, P, name, binary=False, ctx=None):
+    """sv_layers.py:151-196 (SVBlock)."""
+    s, v = x
+    pooled = s.reshape(s.shape[0], -1, s.shape[-1]).mean(dim=1)                       # :179-180
+    gate = torch.sigmoid(F.linear(torch.relu(F.linear(pooled, P[name + ".gate.0.weight"])),
+                                  P[name + ".gate.2.weight"]))                         # :156-161,181
+    gate = gate.view((gate.shape[0],) + (1,) * (v.dim() - 2) + (gate.shape[1],))       # :182-183
+    s_v = vector2scalar(v, P, name + ".v2s", binary=binary, ctx=ctx)                    # :185
+    y = linear(torch.cat([s, s_v], dim=-1), P, name + ".linear1", bw=binary, ba=binary, ctx=ctx)  # :186-187
+    y = batch_norm(y.reshape(-1, y.shape[-1]), P, name + ".bn1", ctx).view(y.shape)     # :188-189
+    y = F.leaky_relu(y, 0.2)                                                            # :190
+    u = linear(v, P, name + ".linear2", bw=binary, ctx=ctx)                             # :192
+    u = vector_bn(u, P, name + ".bn2", ctx) * gate                                      # :193-194
+    return y, u
+
+
+def svfuse(x, P, name, binary, trans_back=False, ctx=None):
+    """sv_layers.py:198-220 (SVFuse)."""
+    s, v = x
+    if trans_back:
+        s_v, z = vector2scalar(v, P, name + ".v2s", binary=binary, trans_back=True, ctx=ctx)
+        return torch.cat([s, s_v], dim=-1), z
+    return torch.cat([s, vector2scalar(v, P, name + ".v2s", binary=binary, ctx=ctx)], dim=-1)
+
+
+def sv_stnkd(x, P, name, binary, ctx=None):
+    """sv_layers.py:222-244 (SV_STNkd)."""
+    for blk in ("conv1", "conv2", "conv3"):
+        x = svblock(x, P, name + "." + blk, binary, ctx)
+    x = svpool(x, dim=1)
+    for blk in ("fc1", "fc2", "fc3"):
+        x = svblock(x, P, name + "." + blk, binary, ctx)
+    return x
+
+
+# ----------------------------------------------------------------------------- callers (models)
+
+def _tap(ctx, key, val):
+    if ctx is not None and ctx.taps is not None:
+        ctx.taps[key] = val
+
+
+def sv_dgcnn_cls(x, P, k=20, binary=True, ctx=None):
+    """sv_dgcnn_cls.py:46-82 (SV_DGCNN_CLS.forward). x: [B,3,N] -> logits [B,num_class]."""
+    B = x.size(0)
+    v = graph_feature(x.unsqueeze(1), k=k, ctx=ctx)
+    s = vector2scalar(v, P, "init_scalar", ctx=ctx)
+    feats = []
+    h = svpool(svblock((s, v), P, "conv1", False, ctx))
+    feats.append(h)
+    _tap(ctx, "x1", h)
+    for i, blk in enumerate(("conv2", "conv3", "conv4")):
+        h = svpool(svblock(graph_feature_sv(h, k=k, ctx=ctx), P, blk, binary, ctx))
+        feats.append(h)
+        _tap(ctx, "x%d" % (i + 2), h)
+    h = svblock(svcat(feats), P, "conv5", binary, ctx)
+    _tap(ctx, "x5", h)
+    f = svfuse(h, P, "svfuse", binary, ctx=ctx)                   # [B,N,1022]
+    g = torch.cat((f.max(dim=1)[0], f.mean(dim=1)), dim=1)        # adaptive max / avg pool over points
+    _tap(ctx, "pooled", g)
+    g = F.leaky_relu(batch_norm(linear(g, P, "linear1", binary, binary, ctx), P, "bn1", ctx), 0.2)
+    g = F.leaky_relu(batch_norm(linear(g, P, "linear2", binary, binary, ctx), P, "bn2", ctx), 0.2)
+    return linear(g, P, "linear3")
+
+
+def sv_pointnet_encoder(x, P, name, k, binary, ctx=None):
+    """sv_pointnet_cls.py:31-60 (SVPointNetEncoder.forward)."""
+    v = graph_feature_cross(x.unsqueeze(1), k=k, ctx=ctx)
+    s = vector2scalar(v, P, name + ".init_scalar", ctx=ctx)
+    h = svpool(svblock((s, v), P, name + ".conv_pos", False, ctx))
+    h = svblock(h, P, name + ".conv1", binary, ctx)
+    g = sv_stnkd(h, P, name + ".fstn", binary, ctx)
+    g = (g[0].unsqueeze(1).expand_as(h[0]), g[1].unsqueeze(1).expand_as(h[1]))
+    h = svcat([h, g])
+    h = svblock(h, P, name + ".conv2", binary, ctx)
+    h = svblock(h, P, name + ".conv3", binary, ctx)
+    m = svpool(h, dim=1, keepdim=True)
+    h = svcat([h, (m[0].expand_as(h[0]), m[1].expand_as(h[1]))])
+    h = svblock(h, P, name + ".conv_fuse", binary, ctx)
+    h = svpool(h, dim=1)
+    return svfuse(h, P, name + ".svfuse", binary, ctx=ctx)
+
+
+def sv_pointnet_cls(x, P, k=20, binary=True, ctx=None):
+    """sv_pointnet_cls.py:75-81 (SV_PointNet_CLS.forward). Dropout is p=0 (binary) or eval-only here."""
+    f = sv_pointnet_encoder(x, P, "feat", k, binary, ctx)
+    f = torch.relu(batch_norm(linear(f, P, "fc1", binary, binary, ctx), P, "bn1", ctx))
+    f = torch.relu(batch_norm(linear(f, P, "fc2", binary, binary, ctx), P, "bn2", ctx))
+    return linear(f, P, "fc3")
+
+
+def sv_dgcnn_pseg(x, l, P, k=40, binary=True, ctx=None):
+    """sv_dgcnn_partseg.py:80-128 (SV_DGCNN_PSEG.forward). x: [B,3,N], l: [B,16] one-hot -> [B,num_part,N]."""
+    B, N = x.size(0), x.size(2)
+    v = graph_feature(x.unsqueeze(1), k=k, ctx=ctx)
+    s = vector2scalar(v, P, "init_scalar", ctx=ctx)
+    feats = []
+    h = svpool(svblock((s, v), P, "conv1", False, ctx))
+    feats.append(h)
+    for blk in ("conv2", "conv3", "conv4"):
+        h = svpool(svblock(graph_feature_sv(h, k=k, ctx=ctx), P, blk, binary, ctx))
+        feats.append(h)
+    h = svcat(feats)
+    fine = svfuse(h, P, "svfuse1", binary, ctx=ctx)                                   # [B,N,544]
+    h = svblock(h, P, "conv5", binary, ctx)
+    pooled = svblock(svpool(h, dim=1, keepdim=True), P, "conv6", binary, ctx)
+    pooled = svfuse(pooled, P, "svfuse2", binary, ctx=ctx)                            # [B,1,520]
+    glob = svfuse(h, P, "svfuse3", binary, ctx=ctx).max(dim=1)[0].unsqueeze(-1)       # [B,1016,1]
+    lab = torch.einsum("oc,bcn->bon", P["conv7.0.weight"][:, :, 0], l.view(B, -1, 1))
+    lab = F.leaky_relu(batch_norm_cf(lab, P, "conv7.1", ctx), 0.2)                    # [B,64,1]
+    g = torch.cat([glob, pooled.transpose(-1, -2), lab], dim=1).expand(-1, -1, N)
+    y = torch.cat([g, fine.transpose(-1, -2)], dim=1)                                 # [B,2144,N]
+    for blk in ("conv8", "conv9", "conv10"):
+        y = conv1d(y, P, blk + ".0", binary, ctx)
+        y = F.leaky_relu(batch_norm_cf(y, P, blk + ".1", ctx), 0.2)
+    return torch.einsum("oc,bcn->bon", P["conv11.weight"][:, :, 0], y)
+
+
+def cal_loss(pred, target, smoothing=True):
+    """utils.py:33-50: label-smoothed cross entropy (eps = 0.2)."""
+    target = target.reshape(-1)
+    if not smoothing:
+        return F.cross_entropy(pred, target)
+    eps, C = 0.2, pred.size(1)
+    soft = torch.full_like(pred, eps / (C - 1))
+    soft.scatter_(1, target.view(-1, 1), 1 - eps)
+    return -(soft * F.log_softmax(pred, dim=1)).sum(dim=1).mean()

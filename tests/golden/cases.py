@@ -1,0 +1,68 @@
+"""Deterministic inputs of the golden cases, shared by make_golden.py (which runs the imported
+reference on them) and by the tests (which run the oracle / the HIP path on them).
+Only inputs are defined here; expected outputs live in the .npz fixtures next to this file."""
+import numpy as np
+import torch
+
+from svnet_amd import synth
+
+SEED = 1234
+
+# (name, B, N, C, k, layout) ; layout "cn" = contiguous [B,C,N] (layer 1), "nc" = transposed view of [B,N,C]
+KNN_CASES = [
+    ("xyz_c3", 2, 1024, 3, 20, "cn"),
+    ("feat_c62", 1, 1024, 62, 20, "nc"),
+    ("feat_c127", 1, 1024, 127, 20, "nc"),
+    ("feat_c80_k40", 1, 512, 80, 40, "nc"),
+    ("feat_c136", 1, 256, 136, 40, "nc"),
+    ("tiny_c20", 2, 64, 20, 8, "nc"),
+    ("tiny_c9_cn", 2, 48, 9, 5, "cn"),
+]
+
+
+def knn_input(name, B, N, C, k, layout):
+    """Returns the [B,C,N] tensor exactly as the reference's knn() receives it."""
+    sid = synth.stream_id("knn/" + name)
+    if layout == "cn":
+        if C == 3:
+            return torch.from_numpy(synth.cloud_batch(SEED, 0, sid % 1000, B, N))
+        return torch.from_numpy(synth.normal(SEED, sid, (B, C, N)) * 0.5)
+    feat = synth.normal(SEED, sid, (B, N, C)) * 0.7
+    return torch.from_numpy(feat).transpose(-1, -2)
+
+
+def t(name, shape, scale=1.0):
+    return torch.from_numpy(synth.normal(SEED, synth.stream_id("op/" + name), shape) * np.float32(scale))
+
+
+def small_cloud(B=2, N=32, tag=0):
+    return torch.from_numpy(synth.cloud_batch(SEED, 100 + tag, 0, B, N))
+
+
+def sv_pair(name, lead, cs, cv, scale=1.0):
+    """(s [*lead,cs], v [*lead,3,cv])"""
+    return t(name + "/s", tuple(lead) + (cs,), scale), t(name + "/v", tuple(lead) + (3, cv), scale)
+
+
+# model-level cases: (tag, model, binary, B, N, k)
+MODEL_CASES = [
+    ("dgcnn_bin_small", "sv_dgcnn_cls", True, 4, 128, 8),
+    ("dgcnn_fp_small", "sv_dgcnn_cls", False, 4, 128, 8),
+    ("dgcnn_bin_full", "sv_dgcnn_cls", True, 2, 1024, 20),
+    ("pointnet_bin_small", "sv_pointnet_cls", True, 4, 128, 8),
+    ("pointnet_fp_small", "sv_pointnet_cls", False, 4, 128, 8),
+    ("pointnet_bin_cfg0", "sv_pointnet_cls", True, 8, 1024, 20),
+    ("pseg_bin_small", "sv_dgcnn_pseg", True, 2, 128, 8),
+    ("pseg_fp_small", "sv_dgcnn_pseg", False, 2, 128, 8),
+]
+
+
+def model_inputs(tag, model, B, N):
+    sid = synth.stream_id("model/" + tag) % 1000
+    x = torch.from_numpy(synth.cloud_batch(SEED, 7, sid, B, N))
+    if model == "sv_dgcnn_pseg":
+        l = torch.from_numpy(synth.category_onehot(SEED, 7, sid, B))
+        y = torch.from_numpy(synth.seg_labels(SEED, 7, sid, B, N))
+        return x, l, y
+    y = torch.from_numpy(synth.class_labels(SEED, 7, sid, B))
+    return x, None, y

@@ -1,0 +1,376 @@
+"""Op-level parity cases, written once against a tiny adapter interface so the SAME case runs on
+  * the imported reference       (ModuleAPI over /root/reference/models, cpu)   -> make_golden.py
+  * the oracle                   (OracleAPI)                                     -> tests, not gpu
+  * the HIP product              (ModuleAPI over svnet_amd.models, cuda)         -> tests, gpu
+Each case returns {name: cpu tensor}.  Gradients are taken of  sum(out * r)  with a fixed r.
+"""
+import contextlib
+import io
+from functools import partial
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from svnet_amd import synth
+from oracle import params as oparams
+from oracle import sv_ref
+
+from . import cases as C
+
+
+# ----------------------------------------------------------------------------- specs of single modules
+
+def module_spec(kind, cfg):
+    s = OrderedDict()
+    if kind == "Linear":
+        cin, cout, bias, bw, ba = cfg
+        oparams._lin(s, "m", cin, cout, bw=bw, ba=ba, bias=bias)
+    elif kind == "Conv1d":
+        cin, cout, binary = cfg
+        oparams._conv(s, "m", cin, cout, binary)
+    elif kind == "VectorBN":
+        oparams._bn(s, "m.bn", cfg[0])
+    elif kind == "Vector2Scalar":
+        v_dim, multi, binary, _tb = cfg
+        oparams._lin(s, "m.linear", v_dim, multi, bw=binary)
+    elif kind == "SVBlock":
+        oparams._svblock(s, "m", cfg[0], cfg[1], cfg[2])
+    elif kind == "SVFuse":
+        v_dim, multi, binary, _tb = cfg
+        oparams._lin(s, "m.v2s.linear", v_dim, multi, bw=binary)
+    elif kind == "SV_STNkd":
+        oparams._stn(s, "m", cfg[0], cfg[1])
+    elif kind == "VectorReLU":
+        pass
+    else:
+        raise KeyError(kind)
+    return OrderedDict((k[2:], v) for k, v in s.items())
+
+
+def module_params(kind, cfg, tag):
+    spec = module_spec(kind, cfg)
+    arrs = synth.synthetic_state(spec, C.SEED + synth.stream_id(tag) % 997)
+    return OrderedDict((k, torch.from_numpy(v.copy())) for k, v in arrs.items())
+
+
+# ----------------------------------------------------------------------------- adapters
+
+class ModuleAPI:
+    """Adapter over a namespace that looks like the reference's models.sv_layers / models.utils.sv_util."""
+
+    def __init__(self, layers, util, device="cpu"):
+        self.L, self.U, self.device = layers, util, torch.device(device)
+
+    def to(self, x):
+        if isinstance(x, (tuple, list)):
+            return tuple(self.to(a) for a in x)
+        return x.to(self.device)
+
+    def leaf(self, x):
+        """device copy that records gradients"""
+        if isinstance(x, (tuple, list)):
+            return tuple(self.leaf(a) for a in x)
+        return x.to(self.device).clone().requires_grad_(True)
+
+    def module(self, kind, cfg, params, train):
+        with contextlib.redirect_stdout(io.StringIO()):          # reference ctors print()
+            if kind == "SVBlock":
+                m = self.L.SVBlock(cfg[0], cfg[1], binary=cfg[2])
+            elif kind == "Linear":
+                m = self.L.Linear(cfg[0], cfg[1], cfg[2], bw=cfg[3], ba=cfg[4])
+            elif kind == "Conv1d":
+                m = self.L.Conv1d(cfg[0], cfg[1], binary=cfg[2])
+            elif kind == "VectorBN":
+                m = self.L.VectorBN(cfg[0])
+            elif kind == "Vector2Scalar":
+                m = self.L.Vector2Scalar(cfg[0], cfg[1], binary=cfg[2], trans_back=cfg[3])
+            elif kind == "SVFuse":
+                m = self.L.SVFuse(cfg[0], cfg[1], cfg[2], trans_back=cfg[3])
+            elif kind == "SV_STNkd":
+                m = self.L.SV_STNkd(cfg[0], cfg[1])
+            elif kind == "VectorReLU":
+                m = self.L.VectorReLU()
+            else:
+                raise KeyError(kind)
+        m.load_state_dict(params, strict=True)
+        m = m.to(self.device)
+        m.train(train)
+        return m
+
+    def param_grads(self, m):
+        return OrderedDict((n, p.grad.detach().cpu()) for n, p in m.named_parameters() if p.grad is not None)
+
+    def buffers(self, m):
+        return OrderedDict((n, b.detach().cpu()) for n, b in m.named_buffers() if b.is_floating_point())
+
+    def graph_feature(self, x, k, **kw):
+        return self.U.get_graph_feature(x, k=k, **kw)
+
+    def graph_feature_cross(self, x, k, **kw):
+        return self.U.get_graph_feature_cross(x, k=k, **kw)
+
+    def graph_feature_sv(self, x, k, **kw):
+        return self.U.get_graph_feature_sv(x, k=k, **kw)
+
+    def knn(self, x, k):
+        return self.U.knn(x, k)
+
+    def svpool(self, x, **kw):
+        return self.U.svpool(x, **kw)
+
+    def svcat(self, xs):
+        return self.U.svcat(xs)
+
+
+class _OracleModule:
+    def __init__(self, kind, cfg, params, train):
+        self.kind, self.cfg = kind, cfg
+        self.P = OrderedDict()
+        for k, v in params.items():
+            tt = v.clone()
+            if tt.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+                tt.requires_grad_(True)
+            self.P["m." + k] = tt
+        self.ctx = sv_ref.Ctx(train=train, collect_bn=True)
+
+    def __call__(self, x):
+        P, ctx, cfg, kind = self.P, self.ctx, self.cfg, self.kind
+        if kind == "SVBlock":
+            return sv_ref.svblock(x, P, "m", cfg[2], ctx)
+        if kind == "Linear":
+            return sv_ref.linear(x, P, "m", bw=cfg[3], ba=cfg[4], ctx=ctx)
+        if kind == "Conv1d":
+            return sv_ref.conv1d(x, P, "m", cfg[2], ctx)
+        if kind == "VectorBN":
+            return sv_ref.vector_bn(x, P, "m", ctx)
+        if kind == "Vector2Scalar":
+            return sv_ref.vector2scalar(x, P, "m", binary=cfg[2], trans_back=cfg[3], ctx=ctx)
+        if kind == "SVFuse":
+            return sv_ref.svfuse(x, P, "m", cfg[2], trans_back=cfg[3], ctx=ctx)
+        if kind == "SV_STNkd":
+            return sv_ref.sv_stnkd(x, P, "m", cfg[1], ctx)
+        if kind == "VectorReLU":
+            return sv_ref.vector_relu(x)
+        raise KeyError(kind)
+
+
+class OracleAPI:
+    device = torch.device("cpu")
+
+    def to(self, x):
+        return x
+
+    def leaf(self, x):
+        if isinstance(x, (tuple, list)):
+            return tuple(self.leaf(a) for a in x)
+        return x.clone().requires_grad_(True)
+
+    def module(self, kind, cfg, params, train):
+        return _OracleModule(kind, cfg, params, train)
+
+    def param_grads(self, m):
+        return OrderedDict((n[2:], p.grad.detach()) for n, p in m.P.items() if p.grad is not None)
+
+    def buffers(self, m):
+        out = OrderedDict()
+        for n, p in m.P.items():
+            if n.endswith(("running_mean", "running_var")):
+                out[n[2:]] = m.ctx.bn_updates.get(n, p).detach()
+        return out
+
+    def graph_feature(self, x, k, **kw):
+        return sv_ref.graph_feature(x, k=k, **kw)
+
+    def graph_feature_cross(self, x, k, **kw):
+        return sv_ref.graph_feature_cross(x, k=k, **kw)
+
+    def graph_feature_sv(self, x, k, **kw):
+        return sv_ref.graph_feature_sv(x, k=k, **kw)
+
+    def knn(self, x, k):
+        return sv_ref.knn_indices(x, k)
+
+    def svpool(self, x, **kw):
+        return sv_ref.svpool(x, **kw)
+
+    def svcat(self, xs):
+        return sv_ref.svcat(xs)
+
+
+# ----------------------------------------------------------------------------- helpers
+
+def _flat(out):
+    return list(out) if isinstance(out, (tuple, list)) else [out]
+
+
+def _record(res, prefix, out):
+    for i, o in enumerate(_flat(out)):
+        res["%s%d" % (prefix, i)] = o.detach().cpu()
+
+
+def _backward(tag, out):
+    total = None
+    for i, o in enumerate(_flat(out)):
+        r = C.t("%s/r%d" % (tag, i), tuple(o.shape)).to(o.device)
+        term = (o * r).sum()
+        total = term if total is None else total + term
+    total.backward()
+
+
+def run_module_case(api, tag, kind, cfg, make_input, train, grads=True, buffers=False, tweak=None, norms_only=False):
+    params = module_params(kind, cfg, tag)
+    if tweak is not None:
+        tweak(params)
+    m = api.module(kind, cfg, params, train)
+    x = make_input()
+    x = api.leaf(x) if grads else api.to(x)
+    out = m(x)
+    res = OrderedDict()
+    _record(res, "out", out)
+    if grads:
+        _backward(tag, out)
+        for i, xi in enumerate(_flat(x)):
+            res["dx%d" % i] = xi.grad.detach().cpu()
+        for n, g in api.param_grads(m).items():
+            res["d:" + n] = g.norm().reshape(1) if norms_only else g
+    if buffers:
+        for n, b in api.buffers(m).items():
+            res["buf:" + n] = b
+    return res
+
+
+# ----------------------------------------------------------------------------- the op cases
+
+def _mk(fn, *a, **kw):
+    return lambda: fn(*a, **kw)
+
+
+def op_cases():
+    """-> OrderedDict name -> callable(api) -> {key: tensor}"""
+    cases = OrderedDict()
+
+    # --- graph features (a2, a3, a4) --------------------------------------------------------
+    def gf_xyz(api, first=False):
+        x = api.to(C.small_cloud(2, 32, 1).unsqueeze(1))
+        return {"out0": api.graph_feature(x, 6, first=first).cpu()}
+    cases["gf_xyz"] = gf_xyz
+    cases["gf_xyz_first"] = lambda api: gf_xyz(api, first=True)
+
+    def gf_xyz_m2(api):
+        x = api.to(C.t("gf_m2", (2, 1, 6, 24), 0.5))          # num_dims = 2
+        return {"out0": api.graph_feature(x, 5).cpu()}
+    cases["gf_xyz_m2"] = gf_xyz_m2
+
+    def gf_xyz_coord(api):
+        x = api.to(C.t("gf_coord/x", (2, 1, 3, 24), 0.5))
+        xc = api.to(C.small_cloud(2, 24, 3).unsqueeze(1))
+        return {"out0": api.graph_feature(x, 5, x_coord=xc).cpu()}
+    cases["gf_xyz_coord"] = gf_xyz_coord
+
+    def gf_cross(api):
+        x = api.to(C.small_cloud(2, 32, 2).unsqueeze(1))
+        return {"out0": api.graph_feature_cross(x, 6).cpu()}
+    cases["gf_cross"] = gf_cross
+
+    def gf_sv(api):
+        s, v = api.leaf(C.sv_pair("gf_sv", (2, 32), 8, 3))
+        so, vo = api.graph_feature_sv((s, v), 6)
+        res = OrderedDict(out0=so.detach().cpu(), out1=vo.detach().cpu())
+        _backward("gf_sv", (so, vo))
+        res["dx0"], res["dx1"] = s.grad.cpu(), v.grad.cpu()
+        return res
+    cases["gf_sv"] = gf_sv
+
+    def gf_sv_idx(api):
+        s, v = api.to(C.sv_pair("gf_sv_idx", (2, 16), 4, 2))
+        idx = api.to(torch.from_numpy(synth.integers(C.SEED, synth.stream_id("gf_sv_idx/i"), (2 * 16 * 3,), 32)))
+        so, vo = api.graph_feature_sv((s, v), 3, idx=idx)
+        return OrderedDict(out0=so.cpu(), out1=vo.cpu())
+    cases["gf_sv_idx"] = gf_sv_idx
+
+    # --- pooling (a5) --------------------------------------------------------------------------
+    def pool(api, dim, keepdim, spool, tag):
+        s, v = C.sv_pair(tag, (2, 6, 5), 7, 3)
+        s = torch.round(s * 2) / 2                               # many exact ties -> first-index rule matters
+        s, v = api.leaf((s, v))
+        so, vo = api.svpool((s, v), dim=dim, keepdim=keepdim, spool=spool)
+        res = OrderedDict(out0=so.detach().cpu(), out1=vo.detach().cpu())
+        _backward(tag, (so, vo))
+        res["dx0"], res["dx1"] = s.grad.cpu(), v.grad.cpu()
+        return res
+    cases["svpool_k_max"] = lambda api: pool(api, 2, False, "max", "pool_a")
+    cases["svpool_n_max_keep"] = lambda api: pool(api, 1, True, "max", "pool_b")
+    cases["svpool_k_mean"] = lambda api: pool(api, 2, False, "mean", "pool_c")
+
+    def cat(api):
+        a = api.to(C.sv_pair("cat_a", (2, 5), 3, 2))
+        b = api.to(C.sv_pair("cat_b", (2, 5), 4, 1))
+        s, v = api.svcat([a, b])
+        return OrderedDict(out0=s.cpu(), out1=v.cpu())
+    cases["svcat"] = cat
+
+    # --- Linear (a6) ---------------------------------------------------------------------------
+    for train in (False, True):
+        sfx = "_train" if train else "_eval"
+
+        def lin_x(name, shape):
+            x = C.t(name, shape, 1.0)
+            x.view(-1)[::7] = 0.0                                # exact zeros -> ternary sign(0)=0 (with beta=0 cols)
+            return x
+
+        def zero_some_beta(params):
+            params["beta"][:, ::3] = 0.0
+        cases["linear_bin" + sfx] = partial(lambda tr, api: run_module_case(
+            api, "linear_bin", "Linear", (37, 11, False, True, True), _mk(lin_x, "linear_bin/x", (2, 5, 37)), tr, tweak=zero_some_beta), train)
+        cases["linear_bin_wide" + sfx] = partial(lambda tr, api: run_module_case(
+            api, "linear_bin_wide", "Linear", (200, 70, False, True, True), _mk(lin_x, "linear_bin_wide/x", (9, 200)), tr, tweak=zero_some_beta), train)
+        cases["linear_bw" + sfx] = partial(lambda tr, api: run_module_case(
+            api, "linear_bw", "Linear", (13, 6, False, True, False), _mk(C.t, "linear_bw/x", (2, 7, 3, 13)), tr), train)
+        cases["linear_fp_bias" + sfx] = partial(lambda tr, api: run_module_case(
+            api, "linear_fp", "Linear", (13, 6, True, False, False), _mk(C.t, "linear_fp/x", (4, 13)), tr), train)
+        cases["conv1d_bin" + sfx] = partial(lambda tr, api: run_module_case(
+            api, "conv1d_bin", "Conv1d", (21, 9, True), _mk(C.t, "conv1d_bin/x", (2, 21, 17)), tr), train)
+        cases["conv1d_fp" + sfx] = partial(lambda tr, api: run_module_case(
+            api, "conv1d_fp", "Conv1d", (21, 9, False), _mk(C.t, "conv1d_fp/x", (2, 21, 17)), tr), train)
+        # --- VectorBN (a8), Vector2Scalar (a9) ------------------------------------------------------
+        cases["vector_bn" + sfx] = partial(lambda tr, api: run_module_case(
+            api, "vector_bn", "VectorBN", (5,), _mk(C.t, "vector_bn/x", (2, 9, 4, 3, 5)), tr, buffers=True), train)
+        for binary in (False, True):
+            b = "_bin" if binary else "_fp"
+            cases["v2s" + b + sfx] = partial(lambda tr, bi, api: run_module_case(
+                api, "v2s", "Vector2Scalar", (5, 3, bi, False), _mk(C.t, "v2s/x", (2, 9, 4, 3, 5)), tr), train, binary)
+            # --- SVBlock (a10) on edge rows (5-D v), point rows (4-D v) and per-cloud rows (3-D v) ------
+            cases["svblock_edge" + b + sfx] = partial(lambda tr, bi, api: run_module_case(
+                api, "svblock_edge", "SVBlock", ((6, 2), (8, 4), bi),
+                _mk(C.sv_pair, "svblock_edge/x", (2, 8, 4), 6, 2), tr, buffers=True), train, binary)
+            cases["svblock_point" + b + sfx] = partial(lambda tr, bi, api: run_module_case(
+                api, "svblock_point", "SVBlock", ((16, 5), (24, 7), bi),
+                _mk(C.sv_pair, "svblock_point/x", (3, 20), 16, 5), tr), train, binary)
+            cases["svblock_cloud" + b + sfx] = partial(lambda tr, bi, api: run_module_case(
+                api, "svblock_cloud", "SVBlock", ((16, 5), (12, 4), bi),
+                _mk(C.sv_pair, "svblock_cloud/x", (6,), 16, 5), tr), train, binary)
+        cases["v2s_transback" + sfx] = partial(lambda tr, api: run_module_case(
+            api, "v2s_tb", "Vector2Scalar", (6, 3, True, True), _mk(C.t, "v2s_tb/x", (2, 7, 3, 6)), tr), train)
+        cases["svfuse_bin" + sfx] = partial(lambda tr, api: run_module_case(
+            api, "svfuse", "SVFuse", (6, 3, True, False), _mk(C.sv_pair, "svfuse/x", (2, 7), 5, 6), tr), train)
+        cases["svfuse_transback" + sfx] = partial(lambda tr, api: run_module_case(
+            api, "svfuse_tb", "SVFuse", (6, 3, True, True), _mk(C.sv_pair, "svfuse_tb/x", (2, 7), 5, 6), tr), train)
+    cases["stn_bin_train"] = lambda api: run_module_case(
+        api, "stn", "SV_STNkd", ((32, 10), True), _mk(C.sv_pair, "stn/x", (3, 12), 32, 10), True, norms_only=True)
+    cases["stn_fp_eval"] = lambda api: run_module_case(
+        api, "stn_fp", "SV_STNkd", ((32, 10), False), _mk(C.sv_pair, "stn_fp/x", (3, 12), 32, 10), False, grads=False)
+    cases["vector_relu"] = lambda api: run_module_case(
+        api, "vrelu", "VectorReLU", (), _mk(C.t, "vrelu/x", (2, 40, 3, 4)), False, grads=False)
+    return cases
+
+
+def to_numpy(res):
+    return {k: v.detach().cpu().numpy() for k, v in res.items()}
+
+
+def max_rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    denom = max(np.abs(b).max(), 1e-12) if b.size else 1.0
+    return float(np.abs(a - b).max() / denom) if b.size else 0.0
