@@ -1,0 +1,174 @@
+/*
+ * svnet_hip.h — C ABI of libsvnet_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * SVNet hot path.  The reference (hellozhuo/svnet) is pure Python/PyTorch and has no FFI of its
+ * own; each entry point below names the reference op chain it replaces (file:line relative to the
+ * reference repository root).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless stated otherwise; tensors are dense row-major fp32,
+ *     indices int64; "rows" M is the product of all leading dimensions
+ *   - the caller owns every buffer (inputs, outputs, workspaces); the library never allocates or
+ *     frees device memory and keeps no device state between calls
+ *   - `stream` is a hipStream_t (passed as void*); calls are asynchronous and ordered on it
+ *   - return value: 0 = ok, <0 = error (SVNET_E_*); svnet_last_error() gives a message for the
+ *     calling thread.  Nothing throws across the ABI.
+ */
+#ifndef SVNET_HIP_H
+#define SVNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVNET_OK 0
+#define SVNET_E_ARG (-1)       /* null pointer / negative size / inconsistent arguments */
+#define SVNET_E_UNSUPPORTED (-2) /* shape outside what the kernels were built for */
+#define SVNET_E_WORKSPACE (-3) /* workspace too small */
+#define SVNET_E_LAUNCH (-4)    /* HIP reported an error at launch */
+
+int svnet_version(void);
+const char* svnet_last_error(void);
+
+/* ------------------------------------------------------------------ k-NN  (models/utils/sv_util.py:19-25, knn)
+ * x is addressed as x[b*sb + n*sn + c*sc] (the [B,C,N] tensor the reference passes, any strides).
+ * xx_mode: 0 = ||x||^2 summed the way ATen reduces an OUTER dim (contiguous [B,C,N]),
+ *          1 = the way ATen reduces the CONTIGUOUS dim (transposed view of [B,N,C])   
+ * idx_out: [B,N,k] int64, cloud-local neighbour ids, nearest first (self first), ties -> lowest id.
+ * Bit-exact against the reference's torch-CPU result for C <= 384, N <= 4096, k <= 64.           */
+size_t svnet_knn_workspace_bytes(int64_t B, int64_t N, int64_t C);
+int svnet_knn_f32(const float* x, int64_t B, int64_t N, int64_t C, int64_t sb, int64_t sn, int64_t sc,
+                  int xx_mode, int k, int64_t* idx_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ edge features from xyz
+ * (sv_util.py:28-62 get_graph_feature, :64-88 get_graph_feature_cross)
+ * x: contiguous [B,3m,N] (channel = m*3+d).  idx: [B,N,k] cloud-local.
+ * mode 0: out[b,n,j,d,:] = [x_j-x_i (m), x_i (m)]            -> [B,N,k,3,2m]
+ * mode 1: (first=True)    [x_j-x_i, mean_j(x_j-x_i)]          -> [B,N,k,3,2m]
+ * mode 2: (cross)         [x_j-x_i, x_i, x_j x x_i]           -> [B,N,k,3,3m]                   */
+int svnet_edge_xyz_f32(const float* x, const int64_t* idx, int64_t B, int64_t N, int64_t k, int64_t m, int mode,
+                       float* out, void* stream);
+
+/* ------------------------------------------------------------------ edge features from (s,v) tables
+ * (sv_util.py:90-116 get_graph_feature_sv; backward = autograd of :106-114, an index_put accumulate)
+ * table: [B*N, G, F]; out: [B*N*k, G, 2F] with out[e,g,:F] = t[j,g,:]-t[i,g,:], out[e,g,F:] = t[i,g,:].
+ * (G,F) = (1,Cs) for scalars, (3,Cv) for vectors.  idx_is_global: idx already holds b*N+j row ids. */
+int svnet_edge_diffcat_fwd_f32(const float* table, const int64_t* idx, int idx_is_global, int64_t B, int64_t N,
+                               int64_t k, int64_t G, int64_t F, float* out, void* stream);
+/* d_table must be zero-filled by the caller; gradients are accumulated with float atomics.          */
+int svnet_edge_diffcat_bwd_f32(const float* d_out, const int64_t* idx, int idx_is_global, int64_t B, int64_t N,
+                               int64_t k, int64_t G, int64_t F, float* d_table, void* stream);
+
+/* ------------------------------------------------------------------ generic fp32 GEMM  C[M,N] = epi(sum_k A(i,k) B(k,j))
+ * Used for every dense contraction of the path: F.linear of sv_layers.py:31,49 and the autograd
+ * products of its backward.  A(i,k) = A[i*a_rs + k*a_cs], B(k,j) = B[k*b_rs + j*b_cs],
+ * C(i,j) = C[i*ldc + j*c_cs].
+ * If a_sign != NULL the A operand is ternary and read from bit-planes instead of fp32:
+ *     A(i,k) = nz(i,k) ? (sign(i,k) ? +1 : -1) : 0,  planes are [*, a_ldw] uint64 words,
+ *     addressed (i, k) when a_planes_trans == 0 and (k, i) when a_planes_trans == 1.
+ * Epilogue, in this order: *alpha, *col_scale[j], +bias[j], *mask(i,j) (mask bit-plane [M, mask_ldw]),
+ * then col_sum[j] += sum_i C(i,j) (float atomics, caller zero-fills), then store (or atomic add when
+ * split_k > 1; the function zero-fills C itself in that case unless accumulate != 0).                */
+typedef struct svnet_gemm_desc {
+    int64_t M, N, K;
+    const float* A; int64_t a_rs, a_cs;
+    const uint64_t* a_sign; const uint64_t* a_nz; int64_t a_ldw; int a_planes_trans;
+    const float* B; int64_t b_rs, b_cs;
+    float* C; int64_t ldc, c_cs;
+    float alpha;
+    const float* col_scale;
+    const float* bias;
+    const uint64_t* mask; int64_t mask_ldw;
+    float* col_sum;
+    int split_k;       /* 0 = choose automatically */
+    int accumulate;    /* C += result */
+} svnet_gemm_desc;
+int svnet_gemm_f32(const svnet_gemm_desc* desc, void* stream);
+
+/* ------------------------------------------------------------------ binarized layers (sv_layers.py:20-53 Linear, :55-78 Conv1d)
+ * Weight preparation (sign(W) with sign(0)=0, clamp/STE mask |W|<=1.2):
+ *   w_sign/w_nz: [O, Kw] uint64 bit-planes (Kw = ceil(K/64)), w_b: [O,K] fp32 in {-1,0,1},
+ *   w_eff: [O,K] = scale[o]*w_b (NULL allowed), any output pointer may be NULL.                    */
+int svnet_binweight_prepare_f32(const float* W, const float* scale, int64_t O, int64_t K, uint64_t* w_sign,
+                                uint64_t* w_nz, float* w_b, float* w_eff, void* stream);
+/* y[m,o] = scale[o] * sum_k sgn(x[m,k]+beta[k]) * sgn(W[o,k])  (+bias[o]) by XNOR/popcount on ternary
+ * bit-planes.  x row stride ldx.  Optional outputs (NULL to skip), each [M,Kw] uint64:
+ *   x_sign, x_nz (sign / non-zero planes of the binarized input), x_ste (|x+beta| <= 1.2).           */
+int svnet_binlinear_fwd_f32(const float* x, int64_t ldx, const float* beta, const uint64_t* w_sign,
+                            const uint64_t* w_nz, const float* scale, const float* bias, int64_t M, int64_t K,
+                            int64_t O, float* y, uint64_t* x_sign, uint64_t* x_nz, uint64_t* x_ste, void* stream);
+/* Chain rule from GX[o,k] = sum_m g[m,o] x_eff[m,k] to the parameters of a bw layer (App. C2):
+ *   dW[o,k] = scale[o]*GX[o,k]*[|W[o,k]|<=1.2],  dscale[o] = sum_k w_b[o,k]*GX[o,k].  dW/dscale are ACCUMULATED. */
+int svnet_binweight_grad_f32(const float* GX, const float* W, const float* scale, int64_t O, int64_t K,
+                             float* dW, float* dscale, void* stream);
+
+/* ------------------------------------------------------------------ Vector2Scalar (sv_layers.py:104-129)
+ * v: [M,3,C]; w_eff: [J,C] effective weights (scale*sign(W) or W); z[m,i,j] = sum_c v[m,i,c] w_eff[j,c];
+ * s[m, d*J+j] = sum_i v[m,i,d] z[m,i,j].  z_out optional ([M,3,J]).  J <= 4, C <= 192.              */
+int svnet_v2s_fwd_f32(const float* v, const float* w_eff, int64_t M, int64_t C, int64_t J, float* s, float* z_out,
+                      void* stream);
+/* ds: [M,C*J]; dz_in: optional gradient arriving at z ([M,3,J]); dv: [M,3,C] (written);
+ * GX: [J,C] accumulated with atomics (caller zero-fills): GX[j,c] = sum_m sum_i dz[m,i,j] v[m,i,c].  */
+int svnet_v2s_bwd_f32(const float* v, const float* w_eff, const float* ds, const float* dz_in, int64_t M, int64_t C,
+                      int64_t J, float* dv, float* GX, void* stream);
+
+/* ------------------------------------------------------------------ BatchNorm1d over rows (+ activation)
+ * (sv_layers.py:166-167,189-190; nn.BatchNorm1d defaults eps=1e-5, momentum=0.1)
+ * stats: sums[0:C] = sum_m x, sums[C:2C] = sum_m x^2 in fp64 (caller zero-fills).
+ * kind 0: x is [M,C];  kind 1: x is [M,3,C] and the statistic is n = ||x[m,:,c]||_2 + 1e-6 (VectorBN, :94). */
+int svnet_colstats_f64(const float* x, int64_t M, int64_t C, int kind, double* sums, void* stream);
+/* mean/invstd from the sums (training) and running-stat update (running_* may be NULL).            */
+int svnet_bn_finalize_f32(const double* sums, int64_t M, int64_t C, float eps, float momentum, float* mean,
+                          float* invstd, float* running_mean, float* running_var, void* stream);
+/* eval mode: mean = running_mean, invstd = 1/sqrt(running_var+eps).                                 */
+int svnet_bn_eval_stats_f32(const float* running_mean, const float* running_var, int64_t C, float eps, float* mean,
+                            float* invstd, void* stream);
+/* y = act((x-mean)*invstd*gamma+beta); act: 0 none, 1 leaky-relu(slope), 2 relu.                    */
+int svnet_bn_act_fwd_f32(const float* x, const float* mean, const float* invstd, const float* gamma,
+                         const float* beta, int64_t M, int64_t C, int act, float slope, float* y, void* stream);
+/* backward, pass 1: red[0:C] = sum g', red[C:2C] = sum g'*xhat (fp32 atomics; caller zero-fills),
+ * g' = g * act'(bn(x)).  pass 2: dx; train_stats=1 subtracts the batch-statistic terms.
+ * dgamma = red[C:2C], dbeta = red[0:C] (the caller adds them to the parameter grads).              */
+int svnet_bn_act_bwd_reduce_f32(const float* g, const float* x, const float* mean, const float* invstd,
+                                const float* gamma, const float* beta, int64_t M, int64_t C, int act, float slope,
+                                float* red, void* stream);
+int svnet_bn_act_bwd_apply_f32(const float* g, const float* x, const float* mean, const float* invstd,
+                               const float* gamma, const float* beta, const float* red, int64_t M, int64_t C, int act,
+                               float slope, int train_stats, float* dx, void* stream);
+
+/* ------------------------------------------------------------------ VectorBN (+ gate)  (sv_layers.py:81-102, :194)
+ * v: [M,3,C]; n = ||v||+1e-6; out = v * (bn(n)/n) * gate[b,c]  (gate NULL = 1; b = m / rows_per_batch). */
+int svnet_vbn_fwd_f32(const float* v, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                      const float* gate, int64_t rows_per_batch, int64_t M, int64_t C, float* out, void* stream);
+/* pass 1: red[0:C] = sum dr, red[C:2C] = sum dr*nhat, dgate[b,c] += sum g*v*q  (caller zero-fills red, dgate) */
+int svnet_vbn_bwd_reduce_f32(const float* g, const float* v, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, const float* gate, int64_t rows_per_batch,
+                             int64_t M, int64_t C, float* red, float* dgate, void* stream);
+int svnet_vbn_bwd_apply_f32(const float* g, const float* v, const float* mean, const float* invstd,
+                            const float* gamma, const float* beta, const float* gate, const float* red,
+                            int64_t rows_per_batch, int64_t M, int64_t C, int train_stats, float* dv, void* stream);
+
+/* ------------------------------------------------------------------ pooling (sv_util.py:118-132 svpool; adaptive pools of sv_dgcnn_cls.py:72-73)
+ * x: [outer, R, inner] -> out [outer, inner].  mode 0 = max (argmax int32 saved, first index on ties),
+ * mode 1 = mean.                                                                                      */
+int svnet_pool_fwd_f32(const float* x, int64_t outer, int64_t R, int64_t inner, int mode, float* out, int32_t* argmax,
+                       void* stream);
+int svnet_pool_bwd_f32(const float* g, const int32_t* argmax, int64_t outer, int64_t R, int64_t inner, int mode,
+                       float* dx, void* stream);
+
+/* ------------------------------------------------------------------ element-wise activations of the gate (sv_layers.py:156-161)
+ * kind 1 = relu, 2 = sigmoid, 3 = leaky-relu(0.2).  Backward uses the OUTPUT y.                      */
+int svnet_act_fwd_f32(const float* x, int64_t n, int kind, float* y, void* stream);
+int svnet_act_bwd_f32(const float* g, const float* y, int64_t n, int kind, float* dx, void* stream);
+
+/* ------------------------------------------------------------------ label-smoothed cross entropy (utils.py:33-50 cal_loss)
+ * logits [R,C], target [R] int64; loss = mean_r -(soft . log_softmax); dlogits = d loss / d logits.   */
+int svnet_smooth_ce_f32(const float* logits, const int64_t* target, int64_t R, int64_t C, float eps, float* loss,
+                        float* dlogits, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVNET_HIP_H */

@@ -1,0 +1,140 @@
+"""ctypes binding of libsvnet_hip.so (the C ABI declared in include/svnet_hip.h).
+
+There is no CPU fallback: if the library is missing, or a tensor is not on a HIP device, the call
+raises.  `build()` compiles the library in-tree with hipcc (gfx950 cross-compiles without a GPU).
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvnet_hip.so")
+_lib = None
+
+c_p = ctypes.c_void_p
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_f = ctypes.c_float
+c_sz = ctypes.c_size_t
+
+
+class GemmDesc(ctypes.Structure):
+    """struct svnet_gemm_desc (include/svnet_hip.h)."""
+    _fields_ = [
+        ("M", c_i64), ("N", c_i64), ("K", c_i64),
+        ("A", c_p), ("a_rs", c_i64), ("a_cs", c_i64),
+        ("a_sign", c_p), ("a_nz", c_p), ("a_ldw", c_i64), ("a_planes_trans", c_int),
+        ("B", c_p), ("b_rs", c_i64), ("b_cs", c_i64),
+        ("C", c_p), ("ldc", c_i64), ("c_cs", c_i64),
+        ("alpha", c_f),
+        ("col_scale", c_p),
+        ("bias", c_p),
+        ("mask", c_p), ("mask_ldw", c_i64),
+        ("col_sum", c_p),
+        ("split_k", c_int),
+        ("accumulate", c_int),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/svnet_hip.h declares
+SIGNATURES = {
+    "svnet_version": (c_int, []),
+    "svnet_last_error": (ctypes.c_char_p, []),
+    "svnet_knn_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
+    "svnet_knn_f32": (c_int, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p, c_p, c_sz, c_p]),
+    "svnet_edge_xyz_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_int, c_p, c_p]),
+    "svnet_edge_diffcat_fwd_f32": (c_int, [c_p, c_p, c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
+    "svnet_edge_diffcat_bwd_f32": (c_int, [c_p, c_p, c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
+    "svnet_gemm_f32": (c_int, [ctypes.POINTER(GemmDesc), c_p]),
+    "svnet_binweight_prepare_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),
+    "svnet_binlinear_fwd_f32": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),
+    "svnet_binweight_grad_f32": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p]),
+    "svnet_v2s_fwd_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
+    "svnet_v2s_bwd_f32": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
+    "svnet_colstats_f64": (c_int, [c_p, c_i64, c_i64, c_int, c_p, c_p]),
+    "svnet_bn_finalize_f32": (c_int, [c_p, c_i64, c_i64, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
+    "svnet_bn_eval_stats_f32": (c_int, [c_p, c_p, c_i64, c_f, c_p, c_p, c_p]),
+    "svnet_bn_act_fwd_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_int, c_f, c_p, c_p]),
+    "svnet_bn_act_bwd_reduce_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_int, c_f, c_p, c_p]),
+    "svnet_bn_act_bwd_apply_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_int, c_f, c_int, c_p, c_p]),
+    "svnet_vbn_fwd_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p]),
+    "svnet_vbn_bwd_reduce_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
+    "svnet_vbn_bwd_apply_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_int, c_p, c_p]),
+    "svnet_pool_fwd_f32": (c_int, [c_p, c_i64, c_i64, c_i64, c_int, c_p, c_p, c_p]),
+    "svnet_pool_bwd_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_int, c_p, c_p]),
+    "svnet_act_fwd_f32": (c_int, [c_p, c_i64, c_int, c_p, c_p]),
+    "svnet_act_bwd_f32": (c_int, [c_p, c_p, c_i64, c_int, c_p, c_p]),
+    "svnet_smooth_ce_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_f, c_p, c_p, c_p]),
+}
+
+
+class SvnetHipError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """Compile svnet_amd/csrc/*.hip into svnet_amd/libsvnet_hip.so (hipcc, --offload-arch=gfx950)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"] + (["-B"] if force else [])
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise SvnetHipError("building libsvnet_hip.so failed")
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SvnetHipError(
+                "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (or make -C svnet_amd/csrc). "
+                "svnet_amd has no CPU fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().svnet_last_error()
+        raise SvnetHipError("%s failed (%d): %s" % (what, code, msg.decode() if msg else "?"))
+
+
+class KernelTimer:
+    """Optional HIP-event stopwatch around ONE entry point (bench.py's roofline leg): events are recorded on
+    the stream the kernel is launched on, immediately before and after the launch call.  `select(args)`
+    may narrow the timing to launches with particular arguments (e.g. one layer's shape)."""
+
+    def __init__(self, name, select=None):
+        self.name, self.select, self.pairs = name, select, []
+
+    def elapsed_ms(self):
+        return [a.elapsed_time(b) for a, b in self.pairs]
+
+
+TIMER = None
+
+
+def call(name, *args):
+    """Invoke one C-ABI entry point and raise on a non-zero return code."""
+    fn = getattr(lib(), name)
+    t = TIMER
+    if t is not None and t.name == name and (t.select is None or t.select(args)):
+        import torch
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st = torch.cuda.current_stream()
+        a.record(st)
+        rc = fn(*args)
+        b.record(st)
+        t.pairs.append((a, b))
+    else:
+        rc = fn(*args)
+    if rc != 0:
+        msg = lib().svnet_last_error()
+        raise SvnetHipError("%s failed (%d): %s" % (name, rc, msg.decode() if msg else "?"))

@@ -1,0 +1,475 @@
+"""torch.autograd.Function wrappers over the C ABI (include/svnet_hip.h).
+
+PyTorch is plumbing here: it owns device memory (every output / workspace is a torch tensor), the
+current HIP stream and the autograd graph.  All arithmetic happens in libsvnet_hip.so.  Every entry
+point refuses CPU tensors — there is deliberately no fallback path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, call
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+# ----------------------------------------------------------------------------- helpers
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _hip(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("svnet_amd: expected a HIP (cuda) tensor, got %s — the product path has no CPU fallback" % t.device)
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise TypeError("svnet_amd: expected float32, got %s" % t.dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def gemm(M, N, K, B, b_rs, b_cs, C, ldc, A=None, a_rs=0, a_cs=0, a_planes=None, c_cs=1, alpha=1.0, col_scale=None,
+         bias=None, mask=None, col_sum=None, split_k=0, accumulate=False):
+    """C(i,j) = epilogue(sum_k A(i,k) B(k,j)); see svnet_gemm_desc."""
+    d = GemmDesc()
+    d.M, d.N, d.K = M, N, K
+    d.A, d.a_rs, d.a_cs = _p(A), a_rs, a_cs
+    if a_planes is not None:
+        sg, nz, ldw, trans = a_planes
+        d.a_sign, d.a_nz, d.a_ldw, d.a_planes_trans = _p(sg), _p(nz), ldw, int(trans)
+    d.B, d.b_rs, d.b_cs = _p(B), b_rs, b_cs
+    d.C, d.ldc, d.c_cs = _p(C), ldc, c_cs
+    d.alpha = alpha
+    d.col_scale, d.bias = _p(col_scale), _p(bias)
+    if mask is not None:
+        d.mask, d.mask_ldw = _p(mask[0]), mask[1]
+    d.col_sum = _p(col_sum)
+    d.split_k, d.accumulate = split_k, int(accumulate)
+    call("svnet_gemm_f32", ctypes.byref(d), _stream())
+
+
+def _words(K):
+    return (K + 63) // 64
+
+
+# ----------------------------------------------------------------------------- k-NN and edge features
+
+def knn(x, k):
+    """x: [B,C,N] (any strides, as sv_util.knn receives it) -> idx [B,N,k] int64, cloud-local, nearest first."""
+    _hip(x)
+    if x.dtype != torch.float32 or x.dim() != 3:
+        raise TypeError("knn expects a float32 [B,C,N] tensor")
+    B, C, N = x.shape
+    xx_mode = 1 if (x.stride(1) == 1 and C > 1) else 0
+    if xx_mode == 0 and not x.is_contiguous():
+        x = x.contiguous()
+    L = _lib.lib()
+    nbytes = L.svnet_knn_workspace_bytes(B, N, C)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    idx = torch.empty((B, N, k), dtype=torch.int64, device=x.device)
+    call("svnet_knn_f32", _p(x), B, N, C, x.stride(0), x.stride(2), x.stride(1), xx_mode, int(k), _p(idx), _p(ws), nbytes,
+                          _stream())
+    return idx
+
+
+def edge_xyz(x, idx, mode):
+    """x: [B,3m,N]; idx [B,N,k] cloud-local; mode 0 plain / 1 first / 2 cross -> [B,N,k,3,W]."""
+    _hip(x, idx)
+    x = _f32c(x.detach())
+    B, C, N = x.shape
+    m = C // 3
+    k = idx.shape[-1]
+    W = (3 if mode == 2 else 2) * m
+    out = torch.empty((B, N, k, 3, W), dtype=torch.float32, device=x.device)
+    call("svnet_edge_xyz_f32", _p(x), _p(idx.contiguous()), B, N, k, m, mode, _p(out), _stream())
+    return out
+
+
+class EdgeDiffcat(torch.autograd.Function):
+    """table [B,N,G,F] -> [B,N,k,G,2F] = [t_j - t_i, t_i]   (sv_util.py:106-114)."""
+
+    @staticmethod
+    def forward(ctx, table, idx, idx_is_global, k):
+        _hip(table, idx)
+        table = _f32c(table)
+        B, N, G, F = table.shape
+        idx = idx.contiguous()
+        out = torch.empty((B, N, k, G, 2 * F), dtype=torch.float32, device=table.device)
+        call("svnet_edge_diffcat_fwd_f32", _p(table), _p(idx), int(idx_is_global), B, N, k, G, F, _p(out), _stream())
+        ctx.save_for_backward(idx)
+        ctx.meta = (B, N, G, F, k, int(idx_is_global))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        B, N, G, F, k, glob = ctx.meta
+        g = _f32c(g)
+        d_table = torch.zeros((B, N, G, F), dtype=torch.float32, device=g.device)
+        call("svnet_edge_diffcat_bwd_f32", _p(g), _p(idx), glob, B, N, k, G, F, _p(d_table), _stream())
+        return d_table, None, None, None
+
+
+# ----------------------------------------------------------------------------- dense layers
+
+class FpLinear(torch.autograd.Function):
+    """y = x W^T (+ b)   (sv_layers.py:30-31 fast path, nn.Linear)."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias):
+        _hip(x, W, bias)
+        x2 = _f32c(x).reshape(-1, x.shape[-1])
+        W = _f32c(W)
+        M, K = x2.shape
+        O = W.shape[0]
+        y = torch.empty((M, O), dtype=torch.float32, device=x.device)
+        gemm(M, O, K, A=x2, a_rs=K, a_cs=1, B=W, b_rs=1, b_cs=K, C=y, ldc=O, bias=bias)
+        ctx.save_for_backward(x2, W)
+        ctx.has_bias = bias is not None
+        ctx.xshape = x.shape
+        return y.view(x.shape[:-1] + (O,))
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, W = ctx.saved_tensors
+        M, K = x2.shape
+        O = W.shape[0]
+        g2 = _f32c(g).reshape(M, O)
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=torch.float32, device=g.device)
+            gemm(M, K, O, A=g2, a_rs=O, a_cs=1, B=W, b_rs=K, b_cs=1, C=dx, ldc=K)
+            dx = dx.view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty((O, K), dtype=torch.float32, device=g.device)
+            gemm(O, K, M, A=g2, a_rs=1, a_cs=O, B=x2, b_rs=K, b_cs=1, C=dW, ldc=K)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = pool_raw(g2, 1, M, O, 1)[0].view(O) * float(M)
+        return dx, dW, db
+
+
+class BwLinear(torch.autograd.Function):
+    """y = (x sign(W)^T) * scale with fp32 activations (sv_layers.py:44-49 with bw only: linear2, v2s.linear, svfuse)."""
+
+    @staticmethod
+    def forward(ctx, x, W, scale):
+        _hip(x, W, scale)
+        x2 = _f32c(x).reshape(-1, x.shape[-1])
+        W = _f32c(W)
+        M, K = x2.shape
+        O = W.shape[0]
+        L = _lib.lib()
+        w_b = torch.empty((O, K), dtype=torch.float32, device=x.device)
+        w_eff = torch.empty((O, K), dtype=torch.float32, device=x.device)
+        sc = _f32c(scale).view(-1)
+        call("svnet_binweight_prepare_f32", _p(W), _p(sc), O, K, None, None, _p(w_b), _p(w_eff), _stream())
+        y = torch.empty((M, O), dtype=torch.float32, device=x.device)
+        gemm(M, O, K, A=x2, a_rs=K, a_cs=1, B=w_b, b_rs=1, b_cs=K, C=y, ldc=O, col_scale=sc)
+        ctx.save_for_backward(x2, W, sc, w_eff)
+        ctx.xshape, ctx.sshape = x.shape, scale.shape
+        return y.view(x.shape[:-1] + (O,))
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, W, sc, w_eff = ctx.saved_tensors
+        M, K = x2.shape
+        O = W.shape[0]
+        g2 = _f32c(g).reshape(M, O)
+        dx = dW = dsc = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=torch.float32, device=g.device)
+            gemm(M, K, O, A=g2, a_rs=O, a_cs=1, B=w_eff, b_rs=K, b_cs=1, C=dx, ldc=K)
+            dx = dx.view(ctx.xshape)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            GX = torch.empty((O, K), dtype=torch.float32, device=g.device)
+            gemm(O, K, M, A=g2, a_rs=1, a_cs=O, B=x2, b_rs=K, b_cs=1, C=GX, ldc=K)
+            dW = torch.zeros((O, K), dtype=torch.float32, device=g.device)
+            dsc = torch.zeros((O,), dtype=torch.float32, device=g.device)
+            call("svnet_binweight_grad_f32", _p(GX), _p(W), _p(sc), O, K, _p(dW), _p(dsc), _stream())
+            dsc = dsc.view(ctx.sshape)
+        return dx, dW, dsc
+
+
+class BinLinear(torch.autograd.Function):
+    """y = (sign(x+beta) sign(W)^T) * scale (+ b): ternary XNOR/popcount (sv_layers.py:35-51 with bw and ba)."""
+
+    @staticmethod
+    def forward(ctx, x, W, beta, scale, bias):
+        _hip(x, W, beta, scale, bias)
+        x2 = _f32c(x).reshape(-1, x.shape[-1])
+        W = _f32c(W)
+        M, K = x2.shape
+        O = W.shape[0]
+        KW = _words(K)
+        dev = x.device
+        L = _lib.lib()
+        need_grad = any(ctx.needs_input_grad)
+        w_sign = torch.empty((O, KW), dtype=torch.int64, device=dev)
+        w_nz = torch.empty((O, KW), dtype=torch.int64, device=dev)
+        sc = _f32c(scale).view(-1)
+        bt = _f32c(beta).view(-1)
+        w_eff = torch.empty((O, K), dtype=torch.float32, device=dev) if need_grad else None
+        call("svnet_binweight_prepare_f32", _p(W), _p(sc), O, K, _p(w_sign), _p(w_nz), None, _p(w_eff), _stream())
+        planes = [torch.empty((M, KW), dtype=torch.int64, device=dev) for _ in range(3)] if need_grad else [None] * 3
+        y = torch.empty((M, O), dtype=torch.float32, device=dev)
+        call("svnet_binlinear_fwd_f32", _p(x2), K, _p(bt), _p(w_sign), _p(w_nz), _p(sc), _p(bias), M, K, O, _p(y),
+                                        _p(planes[0]), _p(planes[1]), _p(planes[2]), _stream())
+        if need_grad:
+            ctx.save_for_backward(W, sc, w_eff, *planes)
+        ctx.meta = (M, K, O, KW, x.shape, beta.shape, scale.shape, bias is not None)
+        return y.view(x.shape[:-1] + (O,))
+
+    @staticmethod
+    def backward(ctx, g):
+        W, sc, w_eff, x_sign, x_nz, x_ste = ctx.saved_tensors
+        M, K, O, KW, xshape, bshape, sshape, has_bias = ctx.meta
+        dev = g.device
+        g2 = _f32c(g).reshape(M, O)
+        dx = dW = dbeta = dsc = dbias = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+            dx = torch.empty((M, K), dtype=torch.float32, device=dev)
+            dbeta = torch.zeros((K,), dtype=torch.float32, device=dev)
+            gemm(M, K, O, A=g2, a_rs=O, a_cs=1, B=w_eff, b_rs=K, b_cs=1, C=dx, ldc=K, mask=(x_ste, KW), col_sum=dbeta)
+            dx = dx.view(xshape)
+            dbeta = dbeta.view(bshape)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[3]:
+            # GX[o,k] = sum_m g[m,o] x_b[m,k], computed as (x_b^T g)[k,o] with the ternary operand on the A side
+            GX = torch.empty((O, K), dtype=torch.float32, device=dev)
+            gemm(K, O, M, a_planes=(x_sign, x_nz, KW, True), B=g2, b_rs=O, b_cs=1, C=GX, ldc=1, c_cs=K)
+            dW = torch.zeros((O, K), dtype=torch.float32, device=dev)
+            dsc = torch.zeros((O,), dtype=torch.float32, device=dev)
+            call("svnet_binweight_grad_f32", _p(GX), _p(W), _p(sc), O, K, _p(dW), _p(dsc), _stream())
+            dsc = dsc.view(sshape)
+        if has_bias and ctx.needs_input_grad[4]:
+            dbias = pool_raw(g2, 1, M, O, 1)[0].view(O) * float(M)
+        return dx, dW, dbeta, dsc, dbias
+
+
+# ----------------------------------------------------------------------------- Vector2Scalar
+
+class V2S(torch.autograd.Function):
+    """Vector2Scalar (sv_layers.py:111-129). Returns (s [...,C*J], z [...,3,J])."""
+
+    @staticmethod
+    def forward(ctx, v, W, scale):
+        _hip(v, W, scale)
+        ctx.set_materialize_grads(False)
+        v3 = _f32c(v).reshape(-1, 3, v.shape[-1])
+        W = _f32c(W)
+        M, _, C = v3.shape
+        J = W.shape[0]
+        L = _lib.lib()
+        if scale is not None:
+            sc = _f32c(scale).view(-1)
+            w_eff = torch.empty((J, C), dtype=torch.float32, device=v.device)
+            call("svnet_binweight_prepare_f32", _p(W), _p(sc), J, C, None, None, None, _p(w_eff), _stream())
+        else:
+            sc, w_eff = None, W
+        s = torch.empty((M, C * J), dtype=torch.float32, device=v.device)
+        z = torch.empty((M, 3, J), dtype=torch.float32, device=v.device)
+        call("svnet_v2s_fwd_f32", _p(v3), _p(w_eff), M, C, J, _p(s), _p(z), _stream())
+        ctx.save_for_backward(v3, W, w_eff, sc)
+        ctx.vshape = v.shape
+        ctx.sshape = None if scale is None else scale.shape
+        lead = v.shape[:-2]
+        return s.view(lead + (C * J,)), z.view(lead + (3, J))
+
+    @staticmethod
+    def backward(ctx, gs, gz):
+        v3, W, w_eff, sc = ctx.saved_tensors
+        M, _, C = v3.shape
+        J = W.shape[0]
+        L = _lib.lib()
+        gs2 = torch.zeros((M, C * J), dtype=torch.float32, device=v3.device) if gs is None else _f32c(gs).reshape(M, C * J)
+        gz2 = None if gz is None else _f32c(gz).reshape(M, 3, J)
+        dv = torch.empty_like(v3)
+        GX = torch.zeros((J, C), dtype=torch.float32, device=v3.device)
+        call("svnet_v2s_bwd_f32", _p(v3), _p(w_eff), _p(gs2), _p(gz2), M, C, J, _p(dv), _p(GX), _stream())
+        dW, dsc = GX, None
+        if sc is not None:
+            dW = torch.zeros((J, C), dtype=torch.float32, device=v3.device)
+            dsc = torch.zeros((J,), dtype=torch.float32, device=v3.device)
+            call("svnet_binweight_grad_f32", _p(GX), _p(W), _p(sc), J, C, _p(dW), _p(dsc), _stream())
+            dsc = dsc.view(ctx.sshape)
+        return dv.view(ctx.vshape), dW, dsc
+
+
+# ----------------------------------------------------------------------------- normalisation
+
+def _batch_stats(x, M, C, kind, running_mean, running_var, training, momentum, eps):
+    L = _lib.lib()
+    dev = x.device
+    mean = torch.empty((C,), dtype=torch.float32, device=dev)
+    invstd = torch.empty((C,), dtype=torch.float32, device=dev)
+    if training:
+        sums = torch.zeros((2 * C,), dtype=torch.float64, device=dev)
+        call("svnet_colstats_f64", _p(x), M, C, kind, _p(sums), _stream())
+        call("svnet_bn_finalize_f32", _p(sums), M, C, eps, momentum, _p(mean), _p(invstd), _p(running_mean), _p(running_var),
+                                      _stream())
+    else:
+        call("svnet_bn_eval_stats_f32", _p(running_mean), _p(running_var), C, eps, _p(mean), _p(invstd), _stream())
+    return mean, invstd
+
+
+class BNAct(torch.autograd.Function):
+    """BatchNorm1d over rows (+ LeakyReLU / ReLU): sv_layers.py:189-190, sv_dgcnn_cls.py:76-78."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, act, slope):
+        _hip(x, gamma, beta)
+        x2 = _f32c(x).reshape(-1, x.shape[-1])
+        M, C = x2.shape
+        mean, invstd = _batch_stats(x2, M, C, 0, running_mean, running_var, training, BN_MOMENTUM, BN_EPS)
+        y = torch.empty_like(x2)
+        call("svnet_bn_act_fwd_f32", _p(x2), _p(mean), _p(invstd), _p(gamma), _p(beta), M, C, act, slope, _p(y), _stream())
+        ctx.save_for_backward(x2, mean, invstd, gamma, beta)
+        ctx.meta = (M, C, act, slope, bool(training), x.shape)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, mean, invstd, gamma, beta = ctx.saved_tensors
+        M, C, act, slope, training, xshape = ctx.meta
+        L = _lib.lib()
+        g2 = _f32c(g).reshape(M, C)
+        red = torch.zeros((2 * C,), dtype=torch.float32, device=g.device)
+        call("svnet_bn_act_bwd_reduce_f32", _p(g2), _p(x2), _p(mean), _p(invstd), _p(gamma), _p(beta), M, C, act, slope, _p(red),
+                                            _stream())
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x2)
+            call("svnet_bn_act_bwd_apply_f32", _p(g2), _p(x2), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(red), M, C, act, slope,
+                                               int(training), _p(dx), _stream())
+            dx = dx.view(xshape)
+        return dx, red[C:], red[:C], None, None, None, None, None
+
+
+class VBN(torch.autograd.Function):
+    """VectorBN (+ gate): out = v * BN(|v|+eps) / (|v|+eps) * gate   (sv_layers.py:86-102, :194)."""
+
+    @staticmethod
+    def forward(ctx, v, gamma, beta, running_mean, running_var, gate, rows_per_batch, training):
+        _hip(v, gamma, beta, gate)
+        v3 = _f32c(v).reshape(-1, 3, v.shape[-1])
+        M, _, C = v3.shape
+        mean, invstd = _batch_stats(v3, M, C, 1, running_mean, running_var, training, BN_MOMENTUM, BN_EPS)
+        gate2 = None if gate is None else _f32c(gate).reshape(-1, C)
+        out = torch.empty_like(v3)
+        call("svnet_vbn_fwd_f32", _p(v3), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(gate2), rows_per_batch, M, C, _p(out),
+                                           _stream())
+        ctx.save_for_backward(v3, mean, invstd, gamma, beta, gate2)
+        ctx.meta = (M, C, rows_per_batch, bool(training), v.shape, None if gate is None else gate.shape)
+        return out.view(v.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        v3, mean, invstd, gamma, beta, gate2 = ctx.saved_tensors
+        M, C, rpb, training, vshape, gshape = ctx.meta
+        L = _lib.lib()
+        g3 = _f32c(g).reshape(M, 3, C)
+        red = torch.zeros((2 * C,), dtype=torch.float32, device=g.device)
+        dgate = None if gate2 is None else torch.zeros_like(gate2)
+        call("svnet_vbn_bwd_reduce_f32", _p(g3), _p(v3), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(gate2), rpb, M, C, _p(red),
+                                         _p(dgate), _stream())
+        dv = None
+        if ctx.needs_input_grad[0]:
+            dv = torch.empty_like(v3)
+            call("svnet_vbn_bwd_apply_f32", _p(g3), _p(v3), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(gate2), _p(red), rpb, M, C,
+                                            int(training), _p(dv), _stream())
+            dv = dv.view(vshape)
+        if dgate is not None:
+            dgate = dgate.view(gshape)
+        return dv, red[C:], red[:C], None, None, dgate, None, None
+
+
+# ----------------------------------------------------------------------------- pooling / activations / loss
+
+def pool_raw(x, outer, R, inner, mode):
+    """x contiguous viewed as [outer,R,inner] -> (out [outer,inner], argmax int32 or None)."""
+    out = torch.empty((outer, inner), dtype=torch.float32, device=x.device)
+    arg = torch.empty((outer, inner), dtype=torch.int32, device=x.device) if mode == 0 else None
+    call("svnet_pool_fwd_f32", _p(x), outer, R, inner, mode, _p(out), _p(arg), _stream())
+    return out, arg
+
+
+class Pool(torch.autograd.Function):
+    """max (first index on ties) or mean over one axis (sv_util.py:125-131)."""
+
+    @staticmethod
+    def forward(ctx, x, dim, mode):
+        _hip(x)
+        x = _f32c(x)
+        dim = dim % x.dim()
+        outer = 1
+        for d in x.shape[:dim]:
+            outer *= d
+        R = x.shape[dim]
+        inner = 1
+        for d in x.shape[dim + 1:]:
+            inner *= d
+        out, arg = pool_raw(x, outer, R, inner, mode)
+        if arg is not None:
+            ctx.save_for_backward(arg)
+        ctx.meta = (outer, R, inner, mode, x.shape)
+        return out.view(x.shape[:dim] + x.shape[dim + 1:])
+
+    @staticmethod
+    def backward(ctx, g):
+        outer, R, inner, mode, xshape = ctx.meta
+        arg = ctx.saved_tensors[0] if mode == 0 else None
+        g2 = _f32c(g).reshape(outer, inner)
+        dx = torch.empty(xshape, dtype=torch.float32, device=g.device)
+        call("svnet_pool_bwd_f32", _p(g2), _p(arg), outer, R, inner, mode, _p(dx), _stream())
+        return dx, None, None
+
+
+class Act(torch.autograd.Function):
+    """kind 1 relu, 2 sigmoid, 3 leaky-relu(0.2) (sv_layers.py:156-161)."""
+
+    @staticmethod
+    def forward(ctx, x, kind):
+        _hip(x)
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        call("svnet_act_fwd_f32", _p(x), x.numel(), kind, _p(y), _stream())
+        ctx.save_for_backward(y)
+        ctx.kind = kind
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = _f32c(g)
+        dx = torch.empty_like(y)
+        call("svnet_act_bwd_f32", _p(g), _p(y), y.numel(), ctx.kind, _p(dx), _stream())
+        return dx, None
+
+
+class SmoothCE(torch.autograd.Function):
+    """Label-smoothed cross entropy, mean over rows (utils.py:33-50 cal_loss)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, eps):
+        _hip(logits, target)
+        lg = _f32c(logits)
+        R, C = lg.shape
+        tg = target.contiguous().view(-1)
+        loss = torch.empty((1,), dtype=torch.float32, device=lg.device)
+        dlog = torch.empty_like(lg)
+        call("svnet_smooth_ce_f32", _p(lg), _p(tg), R, C, eps, _p(loss), _p(dlog), _stream())
+        ctx.save_for_backward(dlog)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlog,) = ctx.saved_tensors
+        return dlog * g, None, None

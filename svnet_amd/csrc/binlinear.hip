@@ -1,0 +1,238 @@
+// Binarized dense layers: ternary bit-planes + XNOR/popcount.
+//
+// Replaces  models/sv_layers.py:29-53 (Linear with bw/ba) and :55-78 (Conv1d binary):
+//   x_b = sign(x + beta)   (sign(0) = 0  -> TERNARY)
+//   w_b = sign(W)
+//   y   = (x_b . w_b^T) * scale (+ bias)
+// With a sign plane s and a non-zero plane z per operand,
+//   dot = popc(zx & zw) - 2 * popc(zx & zw & (sx ^ sw)).
+// This is a bitwise path (no MFMA): per 64-bit word 10 VALU ops, the row bits are produced by
+// wave-wide ballots straight from the coalesced fp32 row loads, the weight words of "my" output
+// channel live in registers for the whole kernel, and row bit-planes are staged in LDS so that all
+// four waves of a workgroup share one packing pass.  HBM traffic = read x once + write y once
+// (+ 3 bits per input element of saved planes in training, instead of keeping the fp32 input).
+#include "common.h"
+
+namespace {
+
+constexpr int ROWS = 64;  // rows per workgroup tile
+
+__global__ __launch_bounds__(256) void binweight_values_kernel(const float* __restrict__ W, const float* __restrict__ scale,
+                                                               int64_t O, int64_t K, float* __restrict__ w_b,
+                                                               float* __restrict__ w_eff) {
+    const int64_t total = O * K;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const float w = W[e];
+        const float s = (w > 0.f) ? 1.f : ((w < 0.f) ? -1.f : 0.f);
+        if (w_b) w_b[e] = s;
+        if (w_eff) w_eff[e] = s * scale[e / K];
+    }
+}
+
+__global__ __launch_bounds__(256) void binweight_pack_kernel(const float* __restrict__ W, int64_t O, int64_t K, int64_t KW,
+                                                             uint64_t* __restrict__ w_sign, uint64_t* __restrict__ w_nz) {
+    const int64_t total = O * KW;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t o = e / KW, w = e - o * KW;
+        uint64_t sg = 0, nz = 0;
+        for (int b = 0; b < 64; ++b) {
+            const int64_t k = w * 64 + b;
+            if (k < K) {
+                const float v = W[o * K + k];
+                if (v > 0.f) sg |= 1ull << b;
+                if (v != 0.f) nz |= 1ull << b;
+            }
+        }
+        w_sign[e] = sg;
+        w_nz[e] = nz;
+    }
+}
+
+// KWM: compile-time bound on the number of 64-bit words per row (KW <= KWM).
+template <int KWM, int PPM>
+__global__ __launch_bounds__(256) void binlinear_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                            const float* __restrict__ beta,
+                                                            const uint64_t* __restrict__ w_sign,
+                                                            const uint64_t* __restrict__ w_nz,
+                                                            const float* __restrict__ scale, const float* __restrict__ bias,
+                                                            int64_t M, int K, int O, int o_base, int KW, int og_shift /*log2 threads per row group*/,
+                                                            float* __restrict__ y, uint64_t* __restrict__ x_sign,
+                                                            uint64_t* __restrict__ x_nz, uint64_t* __restrict__ x_ste) {
+    extern __shared__ uint64_t lds[];  // [3][ROWS][KW]
+    uint64_t* ls = lds;
+    uint64_t* lz = lds + (size_t)ROWS * KW;
+    uint64_t* lt = lds + (size_t)2 * ROWS * KW;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int OG = 1 << og_shift;           // threads that share one row in phase 2 (32..256)
+    const int nsub = 256 >> og_shift;        // row sub-groups in phase 2
+    const int o_in = tid & (OG - 1);
+    const int sub = tid >> og_shift;
+
+    // my output channels' weight words (registers for the whole kernel)
+    uint64_t wsg[PPM][KWM], wnz[PPM][KWM];
+    float sc[PPM], bs[PPM];
+#pragma unroll
+    for (int p = 0; p < PPM; ++p) {
+        const int o = o_base + o_in + 256 * p;
+        const bool ok = (o < O);
+        sc[p] = ok ? scale[o] : 0.f;
+        bs[p] = (ok && bias) ? bias[o] : 0.f;
+#pragma unroll
+        for (int w = 0; w < KWM; ++w) {
+            const bool okw = ok && (w < KW);
+            wsg[p][w] = okw ? w_sign[(size_t)o * KW + w] : 0ull;
+            wnz[p][w] = okw ? w_nz[(size_t)o * KW + w] : 0ull;
+        }
+    }
+
+    const int64_t tiles = (M + ROWS - 1) / ROWS;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t row0 = tile * ROWS;
+        const int rows = (int)min((int64_t)ROWS, M - row0);
+        // ---- phase 1: binarize + pack. wave w handles rows w, w+4, ...
+        for (int r = wave; r < rows; r += 4) {
+            const float* xr = x + (row0 + r) * ldx;
+            for (int w = 0; w < KW; ++w) {
+                const int k = w * 64 + lane;
+                const bool in = k < K;
+                const float t = in ? (xr[k] + beta[k]) : 0.f;
+                const uint64_t sg = __ballot(t > 0.f);
+                const uint64_t nz = __ballot(t != 0.f);
+                const uint64_t st = __ballot(in && (fabsf(t) <= 1.2f));
+                if (lane == 0) {
+                    ls[r * KW + w] = sg;
+                    lz[r * KW + w] = nz;
+                    lt[r * KW + w] = st;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- saved planes (training): the tile's rows are contiguous in the [M,KW] planes
+        if (x_sign) {
+            const int n = rows * KW;
+            for (int e = tid; e < n; e += 256) {
+                x_sign[row0 * KW + e] = ls[e];
+                x_nz[row0 * KW + e] = lz[e];
+                x_ste[row0 * KW + e] = lt[e];
+            }
+        }
+        // ---- phase 2: popcount dot products
+        if (o_base + o_in < O) {
+            for (int r = sub; r < rows; r += nsub) {
+                int cnt[PPM];
+#pragma unroll
+                for (int p = 0; p < PPM; ++p) cnt[p] = 0;
+#pragma unroll
+                for (int w = 0; w < KWM; ++w) {
+                    if (w < KW) {
+                        const uint64_t xs = ls[r * KW + w], xz = lz[r * KW + w];
+#pragma unroll
+                        for (int p = 0; p < PPM; ++p) {
+                            const uint64_t m = xz & wnz[p][w];
+                            const uint64_t dneg = m & (xs ^ wsg[p][w]);
+                            cnt[p] += __popcll(m) - 2 * __popcll(dneg);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < PPM; ++p) {
+                    const int o = o_base + o_in + 256 * p;
+                    if (o < O) y[(row0 + r) * O + o] = (float)cnt[p] * sc[p] + bs[p];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// dW[o,k] += scale[o]*GX[o,k]*[|W|<=1.2] ; dscale[o] += sum_k sign(W[o,k])*GX[o,k].  One wave per output row.
+__global__ __launch_bounds__(256) void binweight_grad_kernel(const float* __restrict__ GX, const float* __restrict__ W,
+                                                             const float* __restrict__ scale, int64_t O, int64_t K,
+                                                             float* __restrict__ dW, float* __restrict__ dscale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t o = wave; o < O; o += nwaves) {
+        const float sc = scale[o];
+        float part = 0.f;
+        for (int64_t k = lane; k < K; k += 64) {
+            const float w = W[o * K + k], g = GX[o * K + k];
+            const float s = (w > 0.f) ? 1.f : ((w < 0.f) ? -1.f : 0.f);
+            part += s * g;
+            if (dW) dW[o * K + k] += (fabsf(w) <= 1.2f) ? sc * g : 0.f;
+        }
+        part = wave_sum(part);
+        if (lane == 0 && dscale) dscale[o] += part;
+    }
+}
+
+template <int KWM, int PPM>
+void launch_fwd(const float* x, int64_t ldx, const float* beta, const uint64_t* w_sign, const uint64_t* w_nz, const float* scale,
+                const float* bias, int64_t M, int K, int O, int KW, float* y, uint64_t* xs, uint64_t* xz, uint64_t* xt,
+                hipStream_t st) {
+    int og_shift = 5;
+    while ((1 << og_shift) < O && og_shift < 8) ++og_shift;
+    const int64_t tiles = svnet_cdiv(M, ROWS);
+    const unsigned grid = (unsigned)(tiles < 256 * 8 ? tiles : 256 * 8);
+    const size_t lds_bytes = (size_t)3 * ROWS * KW * sizeof(uint64_t);
+    for (int o_base = 0; o_base < O; o_base += 256 * PPM)
+        hipLaunchKernelGGL((binlinear_fwd_kernel<KWM, PPM>), dim3(grid), dim3(256), lds_bytes, st, x, ldx, beta, w_sign, w_nz, scale,
+                           bias, M, K, O, o_base, KW, og_shift, y, xs, xz, xt);
+}
+
+}  // namespace
+
+extern "C" int svnet_binweight_prepare_f32(const float* W, const float* scale, int64_t O, int64_t K, uint64_t* w_sign,
+                                           uint64_t* w_nz, float* w_b, float* w_eff, void* stream) {
+    SVNET_REQUIRE(W && O > 0 && K > 0, SVNET_E_ARG, "svnet_binweight_prepare_f32: bad arguments");
+    SVNET_REQUIRE(!w_eff || scale, SVNET_E_ARG, "svnet_binweight_prepare_f32: w_eff needs scale");
+    SVNET_REQUIRE((w_sign == nullptr) == (w_nz == nullptr), SVNET_E_ARG, "svnet_binweight_prepare_f32: need both planes or none");
+    hipStream_t st = (hipStream_t)stream;
+    if (w_b || w_eff) {
+        hipLaunchKernelGGL(binweight_values_kernel, dim3(svnet_grid(O * K, 256)), dim3(256), 0, st, W, scale, O, K, w_b, w_eff);
+        SVNET_CHECK_LAUNCH("binweight_values_kernel");
+    }
+    if (w_sign) {
+        const int64_t KW = svnet_cdiv(K, 64);
+        hipLaunchKernelGGL(binweight_pack_kernel, dim3(svnet_grid(O * KW, 256)), dim3(256), 0, st, W, O, K, KW, w_sign, w_nz);
+        SVNET_CHECK_LAUNCH("binweight_pack_kernel");
+    }
+    return SVNET_OK;
+}
+
+extern "C" int svnet_binlinear_fwd_f32(const float* x, int64_t ldx, const float* beta, const uint64_t* w_sign,
+                                       const uint64_t* w_nz, const float* scale, const float* bias, int64_t M, int64_t K,
+                                       int64_t O, float* y, uint64_t* x_sign, uint64_t* x_nz, uint64_t* x_ste, void* stream) {
+    SVNET_REQUIRE(x && beta && w_sign && w_nz && scale && y, SVNET_E_ARG, "svnet_binlinear_fwd_f32: null pointer");
+    SVNET_REQUIRE(M >= 0 && K > 0 && O > 0 && ldx >= K, SVNET_E_ARG, "svnet_binlinear_fwd_f32: bad sizes");
+    const bool any = x_sign || x_nz || x_ste, all = x_sign && x_nz && x_ste;
+    SVNET_REQUIRE(!any || all, SVNET_E_ARG, "svnet_binlinear_fwd_f32: pass all three saved planes or none");
+    SVNET_REQUIRE(O <= 512, SVNET_E_UNSUPPORTED, "svnet_binlinear_fwd_f32: O=%lld > 512", (long long)O);
+    const int64_t KW = svnet_cdiv(K, 64);
+    SVNET_REQUIRE(KW <= 34, SVNET_E_UNSUPPORTED, "svnet_binlinear_fwd_f32: K=%lld > 2176", (long long)K);
+    if (M == 0) return SVNET_OK;
+    hipStream_t st = (hipStream_t)stream;
+#define SVNET_BL(KWM, PPM) \
+    launch_fwd<KWM, PPM>(x, ldx, beta, w_sign, w_nz, scale, bias, M, (int)K, (int)O, (int)KW, y, x_sign, x_nz, x_ste, st)
+    const bool two = O > 256;
+    if (KW <= 2) { if (two) SVNET_BL(2, 2); else SVNET_BL(2, 1); }
+    else if (KW <= 4) { if (two) SVNET_BL(4, 2); else SVNET_BL(4, 1); }
+    else if (KW <= 8) { if (two) SVNET_BL(8, 2); else SVNET_BL(8, 1); }
+    else if (KW <= 16) SVNET_BL(16, 1);
+    else SVNET_BL(34, 1);
+#undef SVNET_BL
+    SVNET_CHECK_LAUNCH("binlinear_fwd_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_binweight_grad_f32(const float* GX, const float* W, const float* scale, int64_t O, int64_t K,
+                                        float* dW, float* dscale, void* stream) {
+    SVNET_REQUIRE(GX && W && scale && O > 0 && K > 0, SVNET_E_ARG, "svnet_binweight_grad_f32: bad arguments");
+    hipLaunchKernelGGL(binweight_grad_kernel, dim3(svnet_grid(O * 64, 256)), dim3(256), 0, (hipStream_t)stream, GX, W, scale, O, K,
+                       dW, dscale);
+    SVNET_CHECK_LAUNCH("binweight_grad_kernel");
+    return SVNET_OK;
+}

@@ -1,0 +1,52 @@
+// Shared helpers for the gfx950 kernels of libsvnet_hip.so.  CDNA4 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/svnet_hip.h"
+
+#define SVNET_WAVE 64
+
+void svnet_set_error(const char* fmt, ...);
+
+#define SVNET_REQUIRE(cond, code, ...)        \
+    do {                                      \
+        if (!(cond)) {                        \
+            svnet_set_error(__VA_ARGS__);     \
+            return (code);                    \
+        }                                     \
+    } while (0)
+
+#define SVNET_CHECK_LAUNCH(name)                                                   \
+    do {                                                                           \
+        hipError_t e_ = hipGetLastError();                                         \
+        if (e_ != hipSuccess) {                                                    \
+            svnet_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return SVNET_E_LAUNCH;                                                 \
+        }                                                                          \
+    } while (0)
+
+static inline int64_t svnet_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Grid for memory-bound grid-stride kernels: enough blocks to fill 256 CUs x 8, capped.
+static inline unsigned svnet_grid(int64_t work_items, int block, int64_t cap = 256 * 16) {
+    int64_t g = svnet_cdiv(work_items, block);
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+#ifdef __HIPCC__
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+#endif

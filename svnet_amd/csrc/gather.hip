@@ -1,0 +1,135 @@
+// Edge-feature construction for the DGCNN graph (gather) and its backward (scatter-add).
+//
+// Replaces  models/utils/sv_util.py:28-62  (get_graph_feature),  :64-88 (get_graph_feature_cross),
+//           :90-116 (get_graph_feature_sv) and the autograd of the advanced indexing at :106,:111.
+// All three are pure HBM-bound byte movers: the point tables ([B*N, F] rows, <= 17 MB) stay L2 /
+// Infinity-Cache resident, the edge tensors ([B*N*k, 2F]) are written once with fully coalesced
+// stores (consecutive lanes -> consecutive floats of one edge row).
+#include "common.h"
+
+namespace {
+
+// out[e, g, 0:F] = t[j,g,:] - t[i,g,:] ; out[e, g, F:2F] = t[i,g,:]     e = (b*N+i)*k + slot
+__global__ __launch_bounds__(256) void diffcat_fwd_kernel(const float* __restrict__ tab, const int64_t* __restrict__ idx,
+                                                          int idx_is_global, int64_t N, int64_t k, int64_t G, int64_t F,
+                                                          int64_t total, float* __restrict__ out) {
+    const int64_t row_w = G * 2 * F;  // floats per edge row
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = o / row_w;
+        const int64_t r = o - e * row_w;
+        const int64_t g = r / (2 * F);
+        const int64_t f2 = r - g * 2 * F;
+        const int64_t pi = e / k;  // global point row b*N+i
+        const float ci = tab[(pi * G + g) * F + (f2 < F ? f2 : f2 - F)];
+        float val = ci;
+        if (f2 < F) {
+            int64_t j = idx[e];
+            if (!idx_is_global) j += (pi / N) * N;
+            val = tab[(j * G + g) * F + f2] - ci;
+        }
+        out[o] = val;
+    }
+}
+
+// One workgroup per point i (all its k edges): the "centre" part of the gradient is summed over the
+// k slots in registers and added once; the neighbour part goes out as float atomics, one contiguous
+// F-float segment per (edge, g) so that a wave-instruction adds to whole rows.
+__global__ __launch_bounds__(256) void diffcat_bwd_kernel(const float* __restrict__ d_out, const int64_t* __restrict__ idx,
+                                                          int idx_is_global, int64_t N, int64_t k, int64_t G, int64_t F,
+                                                          int64_t points, float* __restrict__ d_tab) {
+    const int64_t GF = G * F;
+    for (int64_t pi = blockIdx.x; pi < points; pi += gridDim.x) {
+        const int64_t base = (pi / N) * N;
+        for (int64_t gf = threadIdx.x; gf < GF; gf += blockDim.x) {
+            const int64_t g = gf / F, f = gf - g * F;
+            float centre = 0.f;
+            for (int64_t s = 0; s < k; ++s) {
+                const int64_t e = pi * k + s;
+                const float* row = d_out + (e * G + g) * 2 * F;
+                const float gd = row[f];       // d/d(t_j - t_i)
+                const float gc = row[F + f];   // d/d(t_i)
+                centre += gc - gd;
+                int64_t j = idx[e];
+                if (!idx_is_global) j += base;
+                atomicAdd(&d_tab[j * GF + gf], gd);
+            }
+            atomicAdd(&d_tab[pi * GF + gf], centre);
+        }
+    }
+}
+
+// xyz features.  x: [B,3m,N] (channel = mm*3+d).  out: [B,N,k,3,W], W = 2m (modes 0,1) or 3m (mode 2).
+__global__ __launch_bounds__(256) void edge_xyz_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
+                                                       int64_t N, int64_t k, int64_t m, int mode, int64_t total,
+                                                       float* __restrict__ out) {
+    const int64_t W = (mode == 2 ? 3 : 2) * m;
+    const int64_t row_w = 3 * W;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = o / row_w;
+        const int64_t r = o - e * row_w;
+        const int64_t d = r / W;
+        const int64_t w = r - d * W;
+        const int64_t pi = e / k;
+        const int64_t b = pi / N, i = pi - b * N;
+        const float* xb = x + b * 3 * m * N;
+        const int64_t part = w / m, mm = w - part * m;
+        float val;
+        if (part == 0) {
+            const int64_t j = idx[e];
+            val = xb[(mm * 3 + d) * N + j] - xb[(mm * 3 + d) * N + i];
+        } else if (part == 1 && mode != 1) {
+            val = xb[(mm * 3 + d) * N + i];
+        } else if (mode == 1) {  // mean over the k neighbours of (x_j - x_i); sequential like torch's mean over a short dim
+            const float ci = xb[(mm * 3 + d) * N + i];
+            float s = 0.f;
+            for (int64_t q = 0; q < k; ++q) s += xb[(mm * 3 + d) * N + idx[pi * k + q]] - ci;
+            val = s / (float)k;
+        } else {  // cross(x_j, x_i)[d]
+            const int64_t j = idx[e];
+            const int64_t d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+            const float a1 = xb[(mm * 3 + d1) * N + j], a2 = xb[(mm * 3 + d2) * N + j];
+            const float b1 = xb[(mm * 3 + d1) * N + i], b2 = xb[(mm * 3 + d2) * N + i];
+            val = a1 * b2 - a2 * b1;
+        }
+        out[o] = val;
+    }
+}
+
+}  // namespace
+
+extern "C" int svnet_edge_diffcat_fwd_f32(const float* table, const int64_t* idx, int idx_is_global, int64_t B, int64_t N,
+                                          int64_t k, int64_t G, int64_t F, float* out, void* stream) {
+    SVNET_REQUIRE(table && idx && out, SVNET_E_ARG, "svnet_edge_diffcat_fwd_f32: null pointer");
+    SVNET_REQUIRE(B >= 0 && N > 0 && k > 0 && G > 0 && F > 0, SVNET_E_ARG, "svnet_edge_diffcat_fwd_f32: bad sizes");
+    const int64_t total = B * N * k * G * 2 * F;
+    if (total == 0) return SVNET_OK;
+    hipLaunchKernelGGL(diffcat_fwd_kernel, dim3(svnet_grid(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, table, idx,
+                       idx_is_global, N, k, G, F, total, out);
+    SVNET_CHECK_LAUNCH("diffcat_fwd_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_edge_diffcat_bwd_f32(const float* d_out, const int64_t* idx, int idx_is_global, int64_t B, int64_t N,
+                                          int64_t k, int64_t G, int64_t F, float* d_table, void* stream) {
+    SVNET_REQUIRE(d_out && idx && d_table, SVNET_E_ARG, "svnet_edge_diffcat_bwd_f32: null pointer");
+    SVNET_REQUIRE(B >= 0 && N > 0 && k > 0 && G > 0 && F > 0, SVNET_E_ARG, "svnet_edge_diffcat_bwd_f32: bad sizes");
+    const int64_t points = B * N;
+    if (points == 0) return SVNET_OK;
+    const int block = (G * F >= 192) ? 256 : (G * F >= 96 ? 128 : 64);
+    hipLaunchKernelGGL(diffcat_bwd_kernel, dim3((unsigned)(points < 65536 ? points : 65536)), dim3(block), 0, (hipStream_t)stream,
+                       d_out, idx, idx_is_global, N, k, G, F, points, d_table);
+    SVNET_CHECK_LAUNCH("diffcat_bwd_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_edge_xyz_f32(const float* x, const int64_t* idx, int64_t B, int64_t N, int64_t k, int64_t m, int mode,
+                                  float* out, void* stream) {
+    SVNET_REQUIRE(x && idx && out, SVNET_E_ARG, "svnet_edge_xyz_f32: null pointer");
+    SVNET_REQUIRE(B >= 0 && N > 0 && k > 0 && m > 0 && mode >= 0 && mode <= 2, SVNET_E_ARG, "svnet_edge_xyz_f32: bad arguments");
+    const int64_t total = B * N * k * 3 * (mode == 2 ? 3 : 2) * m;
+    if (total == 0) return SVNET_OK;
+    hipLaunchKernelGGL(edge_xyz_kernel, dim3(svnet_grid(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, x, idx, N, k, m,
+                       mode, total, out);
+    SVNET_CHECK_LAUNCH("edge_xyz_kernel");
+    return SVNET_OK;
+}

@@ -1,0 +1,176 @@
+// Generic fp32 GEMM with strided / ternary-bit-plane operands and a fused epilogue.
+//
+// Serves every dense contraction on the path: F.linear of sv_layers.py:31,49 (fp layers, the
+// sign-weight vector linear `linear2`, the gate, the classifier) and the autograd products of their
+// backward (dX = G.W, GX = G^T.X with X fp32 or ternary bit-planes).
+// Shapes are tall-and-skinny (M up to 2.6 M rows, N,K <= 2144), i.e. HBM-bound: 64x64x16 LDS tiles,
+// 4x4 register micro-tiles on the vector ALUs, split-K with float atomics when the output is tiny and
+// the reduction long (weight gradients).  (A CDNA4 f32-MFMA variant is the planned upgrade for the
+// two genuinely dense shapes, conv5 505->512 / 83->170.)
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 64, BN = 64, BK = 16, PAD = 4;
+
+struct GemmArgs {
+    svnet_gemm_desc d;
+    int64_t k_chunk;
+    int atomic_out;
+};
+
+__device__ __forceinline__ float tern_elem(const uint64_t* __restrict__ sg, const uint64_t* __restrict__ nz, int64_t ldw,
+                                           int64_t r, int64_t c) {
+    const uint64_t w_nz = nz[r * ldw + (c >> 6)];
+    const uint64_t w_sg = sg[r * ldw + (c >> 6)];
+    const uint64_t bit = 1ull << (c & 63);
+    return (w_nz & bit) ? ((w_sg & bit) ? 1.f : -1.f) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs ga) {
+    const svnet_gemm_desc& d = ga.d;
+    __shared__ float As[BK][BM + PAD];
+    __shared__ float Bs[BK][BN + PAD];
+
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int64_t i0 = (int64_t)blockIdx.x * BM, j0 = (int64_t)blockIdx.y * BN;
+    const int64_t k_begin = (int64_t)blockIdx.z * ga.k_chunk;
+    const int64_t k_end = min(d.K, k_begin + ga.k_chunk);
+
+    float acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
+
+    const bool a_tern = d.a_sign != nullptr;
+    const bool a_k_fast = a_tern ? (d.a_planes_trans == 0) : (d.a_cs == 1 || d.a_rs != 1);
+    const bool b_k_fast = (d.b_rs == 1 && d.b_cs != 1);
+
+    for (int64_t kb = k_begin; kb < k_end; kb += BK) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = tid + 256 * r;
+            int ii, kk;
+            if (a_k_fast) { kk = e & 15; ii = e >> 4; } else { ii = e & 63; kk = e >> 6; }
+            const int64_t gi = i0 + ii, gk = kb + kk;
+            float v = 0.f;
+            if (gi < d.M && gk < k_end) {
+                if (a_tern) v = d.a_planes_trans ? tern_elem(d.a_sign, d.a_nz, d.a_ldw, gk, gi)
+                                                 : tern_elem(d.a_sign, d.a_nz, d.a_ldw, gi, gk);
+                else v = d.A[gi * d.a_rs + gk * d.a_cs];
+            }
+            As[kk][ii] = v;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = tid + 256 * r;
+            int jj, kk;
+            if (b_k_fast) { kk = e & 15; jj = e >> 4; } else { jj = e & 63; kk = e >> 6; }
+            const int64_t gj = j0 + jj, gk = kb + kk;
+            float v = 0.f;
+            if (gj < d.N && gk < k_end) v = d.B[gk * d.b_rs + gj * d.b_cs];
+            Bs[kk][jj] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; ++kk) {
+            const float4 a4 = *reinterpret_cast<const float4*>(&As[kk][ty * 4]);
+            const float4 b4 = *reinterpret_cast<const float4*>(&Bs[kk][tx * 4]);
+            const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+            const float b[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(a[r], b[c], acc[r][c]);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue
+    float colpart[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t gi = i0 + ty * 4 + r;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int64_t gj = j0 + tx * 4 + c;
+            if (gi < d.M && gj < d.N) {
+                float v = acc[r][c] * d.alpha;
+                if (d.col_scale) v *= d.col_scale[gj];
+                if (d.bias && blockIdx.z == 0) v += d.bias[gj];
+                if (d.mask) {
+                    const uint64_t w = d.mask[gi * d.mask_ldw + (gj >> 6)];
+                    if (!((w >> (gj & 63)) & 1ull)) v = 0.f;
+                }
+                colpart[c] += v;
+                float* dst = d.C + gi * d.ldc + gj * d.c_cs;
+                if (ga.atomic_out) atomicAdd(dst, v);
+                else if (d.accumulate) *dst += v;
+                else *dst = v;
+            }
+        }
+    }
+    if (d.col_sum) {
+        float* red = &As[0][0];  // reuse: [16][64]
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[ty * 64 + tx * 4 + c] = colpart[c];
+        __syncthreads();
+        if (tid < 64) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += red[r * 64 + tid];
+            const int64_t gj = j0 + tid;
+            if (gj < d.N) atomicAdd(&d.col_sum[gj], s);
+        }
+    }
+}
+
+__global__ void zero_strided_kernel(float* C, int64_t M, int64_t N, int64_t rs, int64_t cs) {
+    const int64_t total = M * N;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x)
+        C[(o / N) * rs + (o % N) * cs] = 0.f;
+}
+
+}  // namespace
+
+extern "C" int svnet_gemm_f32(const svnet_gemm_desc* desc, void* stream) {
+    SVNET_REQUIRE(desc, SVNET_E_ARG, "svnet_gemm_f32: null descriptor");
+    const svnet_gemm_desc& d = *desc;
+    SVNET_REQUIRE(d.M >= 0 && d.N >= 0 && d.K >= 0, SVNET_E_ARG, "svnet_gemm_f32: negative size");
+    SVNET_REQUIRE(d.C && d.B && (d.A || d.a_sign), SVNET_E_ARG, "svnet_gemm_f32: null operand");
+    SVNET_REQUIRE(!d.a_sign || d.a_nz, SVNET_E_ARG, "svnet_gemm_f32: ternary A needs both planes");
+    SVNET_REQUIRE(d.c_cs != 0 && d.ldc != 0, SVNET_E_ARG, "svnet_gemm_f32: zero C stride");
+    if (d.M == 0 || d.N == 0) return SVNET_OK;
+    hipStream_t st = (hipStream_t)stream;
+
+    GemmArgs ga;
+    ga.d = d;
+    const int64_t tiles = svnet_cdiv(d.M, BM) * svnet_cdiv(d.N, BN);
+    int split = d.split_k;
+    if (split <= 0) {
+        split = 1;
+        if (tiles < 512 && d.K >= 2048) {
+            int64_t want = svnet_cdiv(2048, tiles);
+            int64_t maxs = svnet_cdiv(d.K, 512);
+            split = (int)(want < maxs ? want : maxs);
+            if (split < 1) split = 1;
+        }
+    }
+    int64_t chunk = svnet_cdiv(svnet_cdiv(d.K > 0 ? d.K : 1, split), BK) * BK;
+    split = (int)svnet_cdiv(d.K > 0 ? d.K : 1, chunk);
+    ga.k_chunk = chunk;
+    ga.atomic_out = split > 1;
+    if (ga.atomic_out && !d.accumulate) {
+        hipLaunchKernelGGL(zero_strided_kernel, dim3(svnet_grid(d.M * d.N, 256)), dim3(256), 0, st, d.C, d.M, d.N, d.ldc, d.c_cs);
+        SVNET_CHECK_LAUNCH("zero_strided_kernel");
+    }
+    SVNET_REQUIRE(svnet_cdiv(d.M, BM) <= 2147483647ll && svnet_cdiv(d.N, BN) <= 65535 && split <= 65535, SVNET_E_UNSUPPORTED,
+                  "svnet_gemm_f32: grid too large");
+    dim3 grid((unsigned)svnet_cdiv(d.M, BM), (unsigned)svnet_cdiv(d.N, BN), (unsigned)split);
+    hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, st, ga);
+    SVNET_CHECK_LAUNCH("gemm_kernel");
+    return SVNET_OK;
+}

@@ -1,0 +1,277 @@
+// k-NN in feature space, bit-exact against the reference's torch-CPU evaluation.
+//
+// Replaces  models/utils/sv_util.py:19-25 (knn):  -2*matmul(x^T,x), sum(x**2), pd, topk.
+// Arithmetic contract (re-derived in oracle/knn_exact.c):
+//   dot(i,j)  = sequential fp32 FMA chain over channels, first term a rounded product
+//   xx        = ATen's cascade / ilp-4 / 8-lane vectorised sums of separately rounded squares
+//   pd(i,j)   = fl( fl(-xx[j] + 2*dot) - xx[i] )
+//   idx       = k largest pd, descending, ties -> lowest index
+// This file must be compiled with -ffp-contract=off: every rounding is intentional.
+//
+// Layout in HBM: a prep kernel writes xT[b][c][n] (channel-major, so that the 64 lanes of a wave
+// read 64 consecutive candidates of one channel = one 256-B line) and xx[b][n].  The main kernel
+// never materialises the N x N matrix: a wave keeps Q query rows x (64*T) candidate distances in
+// registers (Q*T accumulators per lane), query values arrive through scalar loads, and the top-k
+// is selected straight from those registers with wave-wide arg-max reductions.
+#include "common.h"
+
+namespace {
+
+struct Cascade {  // ATen multi_row_sum: 4 levels, level step 16
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int i = 0;
+    __device__ __forceinline__ void add(float v) {
+        a0 = __fadd_rn(a0, v);
+        ++i;
+        if ((i & 15) == 0) {
+            a1 = __fadd_rn(a1, a0);
+            a0 = 0.f;
+            if ((i & 0xF0) == 0) {
+                a2 = __fadd_rn(a2, a1);
+                a1 = 0.f;
+                if ((i & 0xF00) == 0) {
+                    a3 = __fadd_rn(a3, a2);
+                    a2 = 0.f;
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ float total() const {
+        return __fadd_rn(__fadd_rn(__fadd_rn(a0, a1), a2), a3);
+    }
+};
+
+// One thread per point: transpose to channel-major and compute ||x||^2 with the exact recipe.
+__global__ __launch_bounds__(256) void knn_prep_kernel(const float* __restrict__ x, int64_t B, int64_t N, int64_t C,
+                                                       int64_t sb, int64_t sn, int64_t sc, int xx_mode,
+                                                       float* __restrict__ xT, float* __restrict__ xx) {
+    const int64_t total = B * N;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = p / N, n = p % N;
+        const float* src = x + b * sb + n * sn;
+        float* dst = xT + b * C * N + n;
+        float result;
+        if (xx_mode == 0) {
+            // outer-dim reduction: columns n < 32*floor(N/32) use one cascade, the rest ATen's row_sum (ilp 4)
+            if (n < (N / 32) * 32) {
+                Cascade cs;
+                for (int64_t c = 0; c < C; ++c) {
+                    float v = src[c * sc];
+                    dst[c * N] = v;
+                    cs.add(__fmul_rn(v, v));
+                }
+                result = cs.total();
+            } else {
+                Cascade part[4];
+                const int64_t ng = C / 4;
+                for (int64_t g = 0; g < ng; ++g) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = src[(4 * g + r) * sc];
+                        dst[(4 * g + r) * N] = v;
+                        part[r].add(__fmul_rn(v, v));
+                    }
+                }
+                float p0 = part[0].total(), p1 = part[1].total(), p2 = part[2].total(), p3 = part[3].total();
+                for (int64_t c = ng * 4; c < C; ++c) {
+                    float v = src[c * sc];
+                    dst[c * N] = v;
+                    p0 = __fadd_rn(p0, __fmul_rn(v, v));
+                }
+                result = __fadd_rn(__fadd_rn(__fadd_rn(p0, p1), p2), p3);
+            }
+        } else if (C < 8) {
+            // contiguous-dim reduction of a row shorter than one 8-lane vector: scalar row_sum (ilp 4)
+            float part[4] = {0.f, 0.f, 0.f, 0.f};
+            const int64_t ng = C / 4;
+            for (int64_t g = 0; g < ng; ++g) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = src[(4 * g + r) * sc];
+                    dst[(4 * g + r) * N] = v;
+                    part[r] = __fadd_rn(part[r], __fmul_rn(v, v));
+                }
+            }
+            for (int64_t c = ng * 4; c < C; ++c) {
+                float v = src[c * sc];
+                dst[c * N] = v;
+                part[0] = __fadd_rn(part[0], __fmul_rn(v, v));
+            }
+            result = __fadd_rn(__fadd_rn(__fadd_rn(part[0], part[1]), part[2]), part[3]);
+        } else {
+            // contiguous-dim reduction: 8-lane vectors, 4 interleaved vector accumulators (C <= 384 < 512,
+            // so the inner cascade never spills a level), leftover vectors into accumulator 0,
+            // lanes combined p0+p1+p2+p3, then scalar tail first, then the 8 lanes in order.
+            float p[4][8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int l = 0; l < 8; ++l) p[r][l] = 0.f;
+            const int64_t nv = C / 8, ng = nv / 4;
+            for (int64_t g = 0; g < ng; ++g) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int l = 0; l < 8; ++l) {
+                        const int64_t c = (4 * g + r) * 8 + l;
+                        float v = src[c * sc];
+                        dst[c * N] = v;
+                        p[r][l] = __fadd_rn(p[r][l], __fmul_rn(v, v));
+                    }
+            }
+            for (int64_t g = ng * 4; g < nv; ++g) {
+#pragma unroll
+                for (int l = 0; l < 8; ++l) {
+                    const int64_t c = g * 8 + l;
+                    float v = src[c * sc];
+                    dst[c * N] = v;
+                    p[0][l] = __fadd_rn(p[0][l], __fmul_rn(v, v));
+                }
+            }
+            float fin = 0.f;
+            for (int64_t c = nv * 8; c < C; ++c) {
+                float v = src[c * sc];
+                dst[c * N] = v;
+                fin = __fadd_rn(fin, __fmul_rn(v, v));
+            }
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                float lane = __fadd_rn(__fadd_rn(__fadd_rn(p[0][l], p[1][l]), p[2][l]), p[3][l]);
+                fin = __fadd_rn(fin, lane);
+            }
+            result = fin;
+        }
+        xx[p] = result;
+    }
+}
+
+// (value, index) arg-max across the wave; larger value wins, equal values -> smaller index.
+__device__ __forceinline__ void wave_argmax(float& v, int& j) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(v, off, 64);
+        const int oj = __shfl_xor(j, off, 64);
+        const bool take = (ov > v) || (ov == v && oj < j);
+        v = take ? ov : v;
+        j = take ? oj : j;
+    }
+}
+
+// T candidates per lane (64*T >= N), Q query rows per wave, 4 waves per workgroup.
+template <int T, int Q>
+__global__ __launch_bounds__(256) void knn_main_kernel(const float* __restrict__ xT, const float* __restrict__ xx,
+                                                       int N, int C, int k, int64_t* __restrict__ idx_out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + wave) * Q;
+    if (q0 >= N) return;  // wave-uniform
+
+    const float* __restrict__ xb = xT + (size_t)b * C * N;
+    const float* __restrict__ xxb = xx + (size_t)b * N;
+
+    float acc[Q][T];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[q][t] = 0.f;
+
+    int qi[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) qi[q] = min(q0 + q, N - 1);
+
+    for (int c = 0; c < C; ++c) {
+        const float* __restrict__ row = xb + (size_t)c * N;
+        float cand[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int j = lane + 64 * t;
+            cand[t] = (j < N) ? row[j] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const float qv = row[qi[q]];  // wave-uniform address -> scalar load
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[q][t] = __builtin_fmaf(qv, cand[t], acc[q][t]);
+        }
+    }
+
+    float xxj[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int j = lane + 64 * t;
+        xxj[t] = (j < N) ? xxb[j] : 0.f;
+    }
+
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        if (q0 + q >= N) break;  // wave-uniform
+        const float xxi = xxb[q0 + q];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int j = lane + 64 * t;
+            const float inner = -2.0f * acc[q][t];                 // exact
+            const float t1 = __fsub_rn(-xxj[t], inner);            // fl(-xx[j] - inner)
+            const float pd = __fsub_rn(t1, xxi);                   // fl(.. - xx[i])
+            acc[q][t] = (j < N) ? pd : -INFINITY;
+        }
+        int mine = 0;
+        for (int s = 0; s < k; ++s) {
+            float bv = acc[q][0];
+            int bt = 0;
+#pragma unroll
+            for (int t = 1; t < T; ++t) {
+                const bool g = acc[q][t] > bv;  // strict: first (lowest j) wins inside a lane
+                bv = g ? acc[q][t] : bv;
+                bt = g ? t : bt;
+            }
+            int bj = lane + 64 * bt;
+            wave_argmax(bv, bj);
+            if (lane == s) mine = bj;
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[q][t] = (bj == lane + 64 * t) ? -INFINITY : acc[q][t];
+        }
+        if (lane < k) idx_out[((size_t)b * N + (q0 + q)) * k + lane] = mine;
+    }
+}
+
+template <int T, int Q>
+void launch_main(const float* xT, const float* xx, int64_t B, int N, int C, int k, int64_t* idx, hipStream_t st) {
+    dim3 grid((unsigned)svnet_cdiv(N, 4 * Q), (unsigned)B);
+    hipLaunchKernelGGL((knn_main_kernel<T, Q>), grid, dim3(256), 0, st, xT, xx, N, C, k, idx);
+}
+
+}  // namespace
+
+extern "C" size_t svnet_knn_workspace_bytes(int64_t B, int64_t N, int64_t C) {
+    if (B < 0 || N < 0 || C < 0) return 0;
+    return (size_t)(B * N * C + B * N) * sizeof(float) + 256;
+}
+
+extern "C" int svnet_knn_f32(const float* x, int64_t B, int64_t N, int64_t C, int64_t sb, int64_t sn, int64_t sc,
+                             int xx_mode, int k, int64_t* idx_out, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+    SVNET_REQUIRE(x && idx_out && workspace, SVNET_E_ARG, "svnet_knn_f32: null pointer");
+    SVNET_REQUIRE(B >= 0 && N > 0 && C > 0 && k > 0 && k <= N, SVNET_E_ARG, "svnet_knn_f32: bad sizes B=%lld N=%lld C=%lld k=%d",
+                  (long long)B, (long long)N, (long long)C, k);
+    SVNET_REQUIRE(xx_mode == 0 || xx_mode == 1, SVNET_E_ARG, "svnet_knn_f32: xx_mode must be 0 or 1");
+    SVNET_REQUIRE(C <= 384, SVNET_E_UNSUPPORTED, "svnet_knn_f32: C=%lld > 384 (bit-exact contract ends where MKL splits K)", (long long)C);
+    SVNET_REQUIRE(N <= 4096 && k <= 64, SVNET_E_UNSUPPORTED, "svnet_knn_f32: N=%lld k=%d outside N<=4096, k<=64", (long long)N, k);
+    SVNET_REQUIRE(workspace_bytes >= svnet_knn_workspace_bytes(B, N, C), SVNET_E_WORKSPACE, "svnet_knn_f32: workspace too small");
+    if (B == 0) return SVNET_OK;
+    hipStream_t st = (hipStream_t)stream;
+    float* xT = (float*)workspace;
+    float* xx = xT + B * N * C;
+    hipLaunchKernelGGL(knn_prep_kernel, dim3(svnet_grid(B * N, 256)), dim3(256), 0, st, x, B, N, C, sb, sn, sc, xx_mode, xT, xx);
+    SVNET_CHECK_LAUNCH("knn_prep_kernel");
+    const int n = (int)N, c = (int)C;
+    if (N <= 64) launch_main<1, 8>(xT, xx, B, n, c, k, idx_out, st);
+    else if (N <= 128) launch_main<2, 8>(xT, xx, B, n, c, k, idx_out, st);
+    else if (N <= 256) launch_main<4, 8>(xT, xx, B, n, c, k, idx_out, st);
+    else if (N <= 512) launch_main<8, 8>(xT, xx, B, n, c, k, idx_out, st);
+    else if (N <= 1024) launch_main<16, 8>(xT, xx, B, n, c, k, idx_out, st);
+    else if (N <= 2048) launch_main<32, 4>(xT, xx, B, n, c, k, idx_out, st);
+    else launch_main<64, 2>(xT, xx, B, n, c, k, idx_out, st);
+    SVNET_CHECK_LAUNCH("knn_main_kernel");
+    return SVNET_OK;
+}

@@ -1,0 +1,371 @@
+// Batch-statistic normalisation over edge / point rows: BatchNorm1d(+LeakyReLU/ReLU) and VectorBN(+gate).
+//
+// Replaces  models/sv_layers.py:189-190 (bn1 + LeakyReLU), :81-102 (VectorBN), :194 (gate scaling) and
+// their autograd.  All kernels are HBM-bound streaming passes over [M,C] / [M,3,C] rows; statistics are
+// accumulated in fp64 (per-thread registers -> LDS -> one atomic per column per workgroup) so that
+// 655 360-row batch statistics do not lose digits to fp32 summation order.
+//
+// Thread mapping for the column-reduction kernels: CW = next pow2 >= min(C,256) consecutive threads
+// cover consecutive channels of one row (coalesced), 256/CW "row lanes" walk the rows.
+#include "common.h"
+
+namespace {
+
+constexpr float VEPS = 1e-6f;  // sv_layers.py:18
+
+struct ColMap {
+    int cw_shift;  // log2(CW)
+    __host__ static ColMap make(int64_t C) {
+        ColMap m;
+        m.cw_shift = 0;
+        while ((1 << m.cw_shift) < C && m.cw_shift < 8) ++m.cw_shift;
+        return m;
+    }
+};
+
+__device__ __forceinline__ float act_grad(float z, int act, float slope) {
+    if (act == 1) return z > 0.f ? 1.f : slope;
+    if (act == 2) return z > 0.f ? 1.f : 0.f;
+    return 1.f;
+}
+
+// Block-level reduction of per-thread doubles over the row lanes, then one atomic per column.
+template <int NQ>
+__device__ __forceinline__ void block_col_reduce(double (&val)[NQ], int col_in, int rl, int RL, int CW, bool col_ok,
+                                                 double* lds /*[NQ][256]*/, double* out0, double* out1, int64_t col,
+                                                 float* fout0, float* fout1) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) lds[q * 256 + rl * CW + col_in] = val[q];
+    __syncthreads();
+    if (rl == 0 && col_ok) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            double s = 0.0;
+            for (int r = 0; r < RL; ++r) s += lds[q * 256 + r * CW + col_in];
+            if (q == 0) {
+                if (out0) atomicAdd(&out0[col], s);
+                if (fout0) atomicAdd(&fout0[col], (float)s);
+            } else {
+                if (out1) atomicAdd(&out1[col], s);
+                if (fout1) atomicAdd(&fout1[col], (float)s);
+            }
+        }
+    }
+}
+
+// sums[0:C] += sum x (or n), sums[C:2C] += sum x^2 (or n^2)
+__global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ x, int64_t M, int64_t C, int kind, int cw_shift,
+                                                       int64_t rows_per_block, double* __restrict__ sums) {
+    __shared__ double lds[2 * 256];
+    const int CW = 1 << cw_shift, RL = 256 >> cw_shift;
+    const int col_in = threadIdx.x & (CW - 1), rl = threadIdx.x >> cw_shift;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(M, r0 + rows_per_block);
+    for (int64_t cbase = 0; cbase < C; cbase += CW) {
+        const int64_t c = cbase + col_in;
+        const bool ok = c < C;
+        double acc[2] = {0.0, 0.0};
+        if (ok) {
+            for (int64_t r = r0 + rl; r < r1; r += RL) {
+                float v;
+                if (kind == 0) {
+                    v = x[r * C + c];
+                } else {
+                    const float a = x[(r * 3 + 0) * C + c], b = x[(r * 3 + 1) * C + c], d = x[(r * 3 + 2) * C + c];
+                    v = sqrtf(a * a + b * b + d * d) + VEPS;
+                }
+                acc[0] += (double)v;
+                acc[1] += (double)v * (double)v;
+            }
+        }
+        block_col_reduce<2>(acc, col_in, rl, RL, CW, ok, lds, sums, sums + C, c, nullptr, nullptr);
+    }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int64_t M, int64_t C, float eps, float momentum,
+                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ rmean,
+                                   float* __restrict__ rvar) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = sums[c] / (double)M;
+    double var = sums[C + c] / (double)M - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+    if (rvar) {
+        const double unb = (M > 1) ? var * ((double)M / (double)(M - 1)) : var;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+}
+
+__global__ void bn_eval_stats_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar, int64_t C, float eps,
+                                     float* __restrict__ mean, float* __restrict__ invstd) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    mean[c] = rmean[c];
+    invstd[c] = 1.f / sqrtf(rvar[c] + eps);
+}
+
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, int64_t total, int64_t C, int act,
+                                                         float slope, float* __restrict__ y) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = e % C;
+        float z = (x[e] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+        if (act == 1) z = z > 0.f ? z : z * slope;
+        else if (act == 2) z = z > 0.f ? z : 0.f;
+        y[e] = z;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                int64_t M, int64_t C, int act, float slope, int cw_shift,
+                                                                int64_t rows_per_block, float* __restrict__ red) {
+    __shared__ double lds[2 * 256];
+    const int CW = 1 << cw_shift, RL = 256 >> cw_shift;
+    const int col_in = threadIdx.x & (CW - 1), rl = threadIdx.x >> cw_shift;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(M, r0 + rows_per_block);
+    for (int64_t cbase = 0; cbase < C; cbase += CW) {
+        const int64_t c = cbase + col_in;
+        const bool ok = c < C;
+        double acc[2] = {0.0, 0.0};
+        if (ok) {
+            const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+            for (int64_t r = r0 + rl; r < r1; r += RL) {
+                const float xh = (x[r * C + c] - mu) * is;
+                const float gp = g[r * C + c] * act_grad(xh * ga + be, act, slope);
+                acc[0] += (double)gp;
+                acc[1] += (double)gp * (double)xh;
+            }
+        }
+        block_col_reduce<2>(acc, col_in, rl, RL, CW, ok, lds, nullptr, nullptr, c, red, red + C);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ red, int64_t M, int64_t C, int act,
+                                                               float slope, int train_stats, float* __restrict__ dx) {
+    const int64_t total = M * C;
+    const float invM = 1.f / (float)M;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = e % C;
+        const float is = invstd[c], ga = gamma[c];
+        const float xh = (x[e] - mean[c]) * is;
+        float gp = g[e] * act_grad(xh * ga + beta[c], act, slope);
+        if (train_stats) gp -= (red[c] + xh * red[C + c]) * invM;
+        dx[e] = gp * ga * is;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ VectorBN
+
+__global__ __launch_bounds__(256) void vbn_fwd_kernel(const float* __restrict__ v, const float* __restrict__ mean,
+                                                      const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ gate,
+                                                      int64_t rpb, int64_t M, int64_t C, float* __restrict__ out) {
+    const int64_t total = M * C;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = e / C, c = e - m * C;
+        const float a = v[(m * 3 + 0) * C + c], b = v[(m * 3 + 1) * C + c], d = v[(m * 3 + 2) * C + c];
+        const float n = sqrtf(a * a + b * b + d * d) + VEPS;
+        const float r = (n - mean[c]) * invstd[c] * gamma[c] + beta[c];
+        float q = r / n;
+        // reference order: v / n * n_bn (* gate)
+        const float gt = gate ? gate[(m / rpb) * C + c] : 1.f;
+        out[(m * 3 + 0) * C + c] = a / n * r * gt;
+        out[(m * 3 + 1) * C + c] = b / n * r * gt;
+        out[(m * 3 + 2) * C + c] = d / n * r * gt;
+        (void)q;
+    }
+}
+
+__global__ __launch_bounds__(256) void vbn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ v,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ gate, int64_t rpb, int64_t M, int64_t C,
+                                                             int cw_shift, int64_t rows_per_block, float* __restrict__ red,
+                                                             float* __restrict__ dgate) {
+    __shared__ double lds[2 * 256];
+    const int CW = 1 << cw_shift, RL = 256 >> cw_shift;
+    const int col_in = threadIdx.x & (CW - 1), rl = threadIdx.x >> cw_shift;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(M, r0 + rows_per_block);
+    for (int64_t cbase = 0; cbase < C; cbase += CW) {
+        const int64_t c = cbase + col_in;
+        const bool ok = c < C;
+        double acc[2] = {0.0, 0.0};
+        if (ok) {
+            const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+            int64_t cur_b = -1;
+            float gsum = 0.f;
+            for (int64_t r = r0 + rl; r < r1; r += RL) {
+                const int64_t b = r / rpb;
+                if (b != cur_b) {
+                    if (cur_b >= 0 && dgate) atomicAdd(&dgate[cur_b * C + c], gsum);
+                    cur_b = b;
+                    gsum = 0.f;
+                }
+                const float a0 = v[(r * 3 + 0) * C + c], a1 = v[(r * 3 + 1) * C + c], a2 = v[(r * 3 + 2) * C + c];
+                const float g0 = g[(r * 3 + 0) * C + c], g1 = g[(r * 3 + 1) * C + c], g2 = g[(r * 3 + 2) * C + c];
+                const float n = sqrtf(a0 * a0 + a1 * a1 + a2 * a2) + VEPS;
+                const float nh = (n - mu) * is;
+                const float rr = nh * ga + be;
+                const float gv = g0 * a0 + g1 * a1 + g2 * a2;  // sum_i g_i v_i
+                const float gt = gate ? gate[b * C + c] : 1.f;
+                gsum += gv * (rr / n);
+                const float dr = gv * gt / n;
+                acc[0] += (double)dr;
+                acc[1] += (double)dr * (double)nh;
+            }
+            if (cur_b >= 0 && dgate) atomicAdd(&dgate[cur_b * C + c], gsum);
+        }
+        block_col_reduce<2>(acc, col_in, rl, RL, CW, ok, lds, nullptr, nullptr, c, red, red + C);
+    }
+}
+
+__global__ __launch_bounds__(256) void vbn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ v,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ gate, const float* __restrict__ red,
+                                                            int64_t rpb, int64_t M, int64_t C, int train_stats,
+                                                            float* __restrict__ dv) {
+    const int64_t total = M * C;
+    const float invM = 1.f / (float)M;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = e / C, c = e - m * C;
+        const float a0 = v[(m * 3 + 0) * C + c], a1 = v[(m * 3 + 1) * C + c], a2 = v[(m * 3 + 2) * C + c];
+        const float gt = gate ? gate[(m / rpb) * C + c] : 1.f;
+        const float g0 = g[(m * 3 + 0) * C + c] * gt, g1 = g[(m * 3 + 1) * C + c] * gt, g2 = g[(m * 3 + 2) * C + c] * gt;
+        const float nv = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+        const float n = nv + VEPS;
+        const float is = invstd[c], ga = gamma[c];
+        const float nh = (n - mean[c]) * is;
+        const float rr = nh * ga + beta[c];
+        const float q = rr / n;
+        const float dq = g0 * a0 + g1 * a1 + g2 * a2;
+        float dr = dq / n;
+        float dn = -dq * rr / (n * n);
+        if (train_stats) dr -= (red[c] + nh * red[C + c]) * invM;
+        dn += dr * ga * is;
+        const float k = nv > 0.f ? dn / nv : 0.f;
+        dv[(m * 3 + 0) * C + c] = g0 * q + k * a0;
+        dv[(m * 3 + 1) * C + c] = g1 * q + k * a1;
+        dv[(m * 3 + 2) * C + c] = g2 * q + k * a2;
+    }
+}
+
+inline void reduce_geometry(int64_t M, int64_t C, int& cw_shift, int64_t& rpb, unsigned& grid) {
+    cw_shift = ColMap::make(C).cw_shift;
+    const int RL = 256 >> cw_shift;
+    int64_t blocks = svnet_cdiv(M, (int64_t)RL * 8);  // >= 8 rows per thread
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    rpb = svnet_cdiv(svnet_cdiv(M, blocks), RL) * RL;
+    grid = (unsigned)svnet_cdiv(M, rpb);
+}
+
+}  // namespace
+
+extern "C" int svnet_colstats_f64(const float* x, int64_t M, int64_t C, int kind, double* sums, void* stream) {
+    SVNET_REQUIRE(x && sums && M >= 0 && C > 0 && (kind == 0 || kind == 1), SVNET_E_ARG, "svnet_colstats_f64: bad arguments");
+    if (M == 0) return SVNET_OK;
+    int cw; int64_t rpb; unsigned grid;
+    reduce_geometry(M, C, cw, rpb, grid);
+    hipLaunchKernelGGL(colstats_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, M, C, kind, cw, rpb, sums);
+    SVNET_CHECK_LAUNCH("colstats_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_bn_finalize_f32(const double* sums, int64_t M, int64_t C, float eps, float momentum, float* mean,
+                                     float* invstd, float* running_mean, float* running_var, void* stream) {
+    SVNET_REQUIRE(sums && mean && invstd && M > 0 && C > 0, SVNET_E_ARG, "svnet_bn_finalize_f32: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)svnet_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, M, C, eps,
+                       momentum, mean, invstd, running_mean, running_var);
+    SVNET_CHECK_LAUNCH("bn_finalize_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_bn_eval_stats_f32(const float* running_mean, const float* running_var, int64_t C, float eps, float* mean,
+                                       float* invstd, void* stream) {
+    SVNET_REQUIRE(running_mean && running_var && mean && invstd && C > 0, SVNET_E_ARG, "svnet_bn_eval_stats_f32: bad arguments");
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((unsigned)svnet_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, running_mean,
+                       running_var, C, eps, mean, invstd);
+    SVNET_CHECK_LAUNCH("bn_eval_stats_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_bn_act_fwd_f32(const float* x, const float* mean, const float* invstd, const float* gamma,
+                                    const float* beta, int64_t M, int64_t C, int act, float slope, float* y, void* stream) {
+    SVNET_REQUIRE(x && mean && invstd && gamma && beta && y && M >= 0 && C > 0, SVNET_E_ARG, "svnet_bn_act_fwd_f32: bad arguments");
+    if (M == 0) return SVNET_OK;
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(svnet_grid(M * C, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, x, mean, invstd,
+                       gamma, beta, M * C, C, act, slope, y);
+    SVNET_CHECK_LAUNCH("bn_act_fwd_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_bn_act_bwd_reduce_f32(const float* g, const float* x, const float* mean, const float* invstd,
+                                           const float* gamma, const float* beta, int64_t M, int64_t C, int act, float slope,
+                                           float* red, void* stream) {
+    SVNET_REQUIRE(g && x && mean && invstd && gamma && beta && red && M >= 0 && C > 0, SVNET_E_ARG, "svnet_bn_act_bwd_reduce_f32: bad arguments");
+    if (M == 0) return SVNET_OK;
+    int cw; int64_t rpb; unsigned grid;
+    reduce_geometry(M, C, cw, rpb, grid);
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, x, mean, invstd, gamma, beta, M, C,
+                       act, slope, cw, rpb, red);
+    SVNET_CHECK_LAUNCH("bn_act_bwd_reduce_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_bn_act_bwd_apply_f32(const float* g, const float* x, const float* mean, const float* invstd,
+                                          const float* gamma, const float* beta, const float* red, int64_t M, int64_t C, int act,
+                                          float slope, int train_stats, float* dx, void* stream) {
+    SVNET_REQUIRE(g && x && mean && invstd && gamma && beta && red && dx && M >= 0 && C > 0, SVNET_E_ARG, "svnet_bn_act_bwd_apply_f32: bad arguments");
+    if (M == 0) return SVNET_OK;
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(svnet_grid(M * C, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, g, x, mean,
+                       invstd, gamma, beta, red, M, C, act, slope, train_stats, dx);
+    SVNET_CHECK_LAUNCH("bn_act_bwd_apply_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_vbn_fwd_f32(const float* v, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                 const float* gate, int64_t rows_per_batch, int64_t M, int64_t C, float* out, void* stream) {
+    SVNET_REQUIRE(v && mean && invstd && gamma && beta && out && M >= 0 && C > 0 && rows_per_batch > 0, SVNET_E_ARG, "svnet_vbn_fwd_f32: bad arguments");
+    if (M == 0) return SVNET_OK;
+    hipLaunchKernelGGL(vbn_fwd_kernel, dim3(svnet_grid(M * C, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, v, mean, invstd,
+                       gamma, beta, gate, rows_per_batch, M, C, out);
+    SVNET_CHECK_LAUNCH("vbn_fwd_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_vbn_bwd_reduce_f32(const float* g, const float* v, const float* mean, const float* invstd,
+                                        const float* gamma, const float* beta, const float* gate, int64_t rows_per_batch,
+                                        int64_t M, int64_t C, float* red, float* dgate, void* stream) {
+    SVNET_REQUIRE(g && v && mean && invstd && gamma && beta && red && M >= 0 && C > 0 && rows_per_batch > 0, SVNET_E_ARG, "svnet_vbn_bwd_reduce_f32: bad arguments");
+    if (M == 0) return SVNET_OK;
+    int cw; int64_t rpb; unsigned grid;
+    reduce_geometry(M, C, cw, rpb, grid);
+    hipLaunchKernelGGL(vbn_bwd_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, v, mean, invstd, gamma, beta, gate,
+                       rows_per_batch, M, C, cw, rpb, red, dgate);
+    SVNET_CHECK_LAUNCH("vbn_bwd_reduce_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_vbn_bwd_apply_f32(const float* g, const float* v, const float* mean, const float* invstd,
+                                       const float* gamma, const float* beta, const float* gate, const float* red,
+                                       int64_t rows_per_batch, int64_t M, int64_t C, int train_stats, float* dv, void* stream) {
+    SVNET_REQUIRE(g && v && mean && invstd && gamma && beta && red && dv && M >= 0 && C > 0 && rows_per_batch > 0, SVNET_E_ARG, "svnet_vbn_bwd_apply_f32: bad arguments");
+    if (M == 0) return SVNET_OK;
+    hipLaunchKernelGGL(vbn_bwd_apply_kernel, dim3(svnet_grid(M * C, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, g, v, mean,
+                       invstd, gamma, beta, gate, red, rows_per_batch, M, C, train_stats, dv);
+    SVNET_CHECK_LAUNCH("vbn_bwd_apply_kernel");
+    return SVNET_OK;
+}

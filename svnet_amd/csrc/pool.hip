@@ -1,0 +1,186 @@
+// Neighbour / point pooling, gate activations and the loss.
+//
+// Replaces  models/utils/sv_util.py:118-132 (svpool: max over scalars, mean over vectors),
+//           models/sv_dgcnn_cls.py:72-73 (adaptive max / avg pool over points),
+//           the ReLU / Sigmoid of the gate (sv_layers.py:156-161) and utils.py:33-50 (cal_loss).
+// x is viewed as [outer, R, inner]; lanes run over `inner` (coalesced), the reduced axis R is walked
+// sequentially (R = k = 20..40 for neighbour pooling).  Long reductions with few outputs (gate mean over
+// 20 480 edge rows) are split over workgroups and combined with float atomics.
+#include <float.h>
+
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ x, int64_t outer, int64_t R, int64_t inner,
+                                                       int mode, float* __restrict__ out, int32_t* __restrict__ argmax) {
+    const int64_t total = outer * inner;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t o = e / inner, i = e - o * inner;
+        const float* p = x + o * R * inner + i;
+        if (mode == 0) {
+            float best = p[0];
+            int32_t bi = 0;
+            for (int64_t r = 1; r < R; ++r) {
+                const float v = p[r * inner];
+                if (v > best || (v != v && best == best)) {  // strict: first index wins ties; NaN propagates like torch
+                    best = v;
+                    bi = (int32_t)r;
+                }
+            }
+            out[e] = best;
+            if (argmax) argmax[e] = bi;
+        } else {
+            float s = 0.f;
+            for (int64_t r = 0; r < R; ++r) s += p[r * inner];
+            out[e] = s / (float)R;
+        }
+    }
+}
+
+// mean with a long reduced axis: grid (chunks, outer); partial sums -> atomics (out pre-zeroed)
+__global__ __launch_bounds__(256) void pool_mean_split_kernel(const float* __restrict__ x, int64_t R, int64_t inner,
+                                                              int64_t rows_per_chunk, float* __restrict__ out) {
+    const int64_t o = blockIdx.y;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+    const float invR = 1.f / (float)R;
+    for (int64_t i = threadIdx.x; i < inner; i += blockDim.x) {
+        const float* p = x + o * R * inner + i;
+        float s = 0.f;
+        for (int64_t r = r0; r < r1; ++r) s += p[r * inner];
+        atomicAdd(&out[o * inner + i], s * invR);
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ g, const int32_t* __restrict__ argmax,
+                                                       int64_t outer, int64_t R, int64_t inner, int mode,
+                                                       float* __restrict__ dx) {
+    const int64_t total = outer * R * inner;
+    const float invR = 1.f / (float)R;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e % inner;
+        const int64_t orr = e / inner;
+        const int64_t r = orr % R, o = orr / R;
+        const float gv = g[o * inner + i];
+        dx[e] = (mode == 0) ? ((argmax[o * inner + i] == (int32_t)r) ? gv : 0.f) : gv * invR;
+    }
+}
+
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, int64_t n, int kind, float* __restrict__ y) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[e];
+        float r;
+        if (kind == 1) r = v > 0.f ? v : 0.f;
+        else if (kind == 2) r = 1.f / (1.f + expf(-v));
+        else r = v > 0.f ? v : 0.2f * v;
+        y[e] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y, int64_t n, int kind,
+                                                      float* __restrict__ dx) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const float v = y[e];
+        float d;
+        if (kind == 1) d = v > 0.f ? 1.f : 0.f;
+        else if (kind == 2) d = v * (1.f - v);
+        else d = v > 0.f ? 1.f : 0.2f;
+        dx[e] = g[e] * d;
+    }
+}
+
+// one wave per row: log-softmax, smoothed target, loss and gradient
+__global__ __launch_bounds__(256) void smooth_ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                        int64_t R, int64_t C, float eps, float* __restrict__ loss,
+                                                        float* __restrict__ dlogits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const float off = eps / (float)(C - 1), on = 1.f - eps;
+    const float invR = 1.f / (float)R;
+    float local = 0.f;
+    for (int64_t r = wave; r < R; r += nwaves) {
+        const float* row = logits + r * C;
+        float mx = -FLT_MAX;
+        for (int64_t c = lane; c < C; c += 64) mx = fmaxf(mx, row[c]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float se = 0.f;
+        for (int64_t c = lane; c < C; c += 64) se += expf(row[c] - mx);
+        se = wave_sum(se);
+        const float lse = logf(se) + mx;
+        const int64_t t = target[r];
+        float part = 0.f;
+        for (int64_t c = lane; c < C; c += 64) {
+            const float logp = row[c] - lse;
+            const float soft = (c == t) ? on : off;
+            part -= soft * logp;
+            if (dlogits) dlogits[r * C + c] = (expf(logp) - soft) * invR;
+        }
+        local += wave_sum(part);
+    }
+    if (lane == 0 && local != 0.f) atomicAdd(loss, local * invR);
+}
+
+}  // namespace
+
+extern "C" int svnet_pool_fwd_f32(const float* x, int64_t outer, int64_t R, int64_t inner, int mode, float* out, int32_t* argmax,
+                                  void* stream) {
+    SVNET_REQUIRE(x && out && outer >= 0 && R > 0 && inner > 0 && (mode == 0 || mode == 1), SVNET_E_ARG, "svnet_pool_fwd_f32: bad arguments");
+    if (outer == 0) return SVNET_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = outer * inner;
+    if (mode == 1 && R >= 256 && total < 256 * 256) {
+        hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * total, st);
+        SVNET_REQUIRE(e == hipSuccess, SVNET_E_LAUNCH, "svnet_pool_fwd_f32: memset failed");
+        int64_t chunks = svnet_cdiv(256 * 8, outer);
+        if (chunks > svnet_cdiv(R, 32)) chunks = svnet_cdiv(R, 32);
+        const int64_t rpc = svnet_cdiv(R, chunks);
+        chunks = svnet_cdiv(R, rpc);
+        SVNET_REQUIRE(outer <= 65535, SVNET_E_UNSUPPORTED, "svnet_pool_fwd_f32: outer too large for split mean");
+        const int block = inner >= 256 ? 256 : (inner >= 128 ? 128 : 64);
+        hipLaunchKernelGGL(pool_mean_split_kernel, dim3((unsigned)chunks, (unsigned)outer), dim3(block), 0, st, x, R, inner, rpc, out);
+        SVNET_CHECK_LAUNCH("pool_mean_split_kernel");
+        return SVNET_OK;
+    }
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(svnet_grid(total, 256, 256 * 32)), dim3(256), 0, st, x, outer, R, inner, mode, out, argmax);
+    SVNET_CHECK_LAUNCH("pool_fwd_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_pool_bwd_f32(const float* g, const int32_t* argmax, int64_t outer, int64_t R, int64_t inner, int mode,
+                                  float* dx, void* stream) {
+    SVNET_REQUIRE(g && dx && outer >= 0 && R > 0 && inner > 0 && (mode == 1 || (mode == 0 && argmax)), SVNET_E_ARG, "svnet_pool_bwd_f32: bad arguments");
+    if (outer == 0) return SVNET_OK;
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(svnet_grid(outer * R * inner, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, g, argmax,
+                       outer, R, inner, mode, dx);
+    SVNET_CHECK_LAUNCH("pool_bwd_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_act_fwd_f32(const float* x, int64_t n, int kind, float* y, void* stream) {
+    SVNET_REQUIRE(x && y && n >= 0 && kind >= 1 && kind <= 3, SVNET_E_ARG, "svnet_act_fwd_f32: bad arguments");
+    if (n == 0) return SVNET_OK;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(svnet_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, n, kind, y);
+    SVNET_CHECK_LAUNCH("act_fwd_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_act_bwd_f32(const float* g, const float* y, int64_t n, int kind, float* dx, void* stream) {
+    SVNET_REQUIRE(g && y && dx && n >= 0 && kind >= 1 && kind <= 3, SVNET_E_ARG, "svnet_act_bwd_f32: bad arguments");
+    if (n == 0) return SVNET_OK;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(svnet_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, g, y, n, kind, dx);
+    SVNET_CHECK_LAUNCH("act_bwd_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_smooth_ce_f32(const float* logits, const int64_t* target, int64_t R, int64_t C, float eps, float* loss,
+                                   float* dlogits, void* stream) {
+    SVNET_REQUIRE(logits && target && loss && R > 0 && C > 1, SVNET_E_ARG, "svnet_smooth_ce_f32: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
+    SVNET_REQUIRE(e == hipSuccess, SVNET_E_LAUNCH, "svnet_smooth_ce_f32: memset failed");
+    hipLaunchKernelGGL(smooth_ce_kernel, dim3(svnet_grid(R * 64, 256, 1024)), dim3(256), 0, st, logits, target, R, C, eps, loss, dlogits);
+    SVNET_CHECK_LAUNCH("smooth_ce_kernel");
+    return SVNET_OK;
+}

@@ -1,0 +1,194 @@
+// Vector2Scalar: rotation-invariant scalars from vector channels.
+//
+// Replaces  models/sv_layers.py:111-129 (Vector2Scalar.forward):
+//   z[m,i,j] = sum_c v[m,i,c] * w_eff[j,c]          (F.linear on the last dim, :116; w_eff = scale*sign(W) or W)
+//   s[m,c*J+j] = sum_i v[m,i,c] * z[m,i,j]          (einsum, :119-123)
+// One group of G lanes owns one row; lane g holds channels g, g+G, g+2G (<= 3 per lane) of the three
+// spatial components in registers, the 3xJ matrix z is reduced across the group with xor-shuffles, and
+// each lane writes the J contiguous outputs of its channels.  One pass over v, one pass over s: HBM-bound.
+#include "common.h"
+
+namespace {
+
+constexpr int J = 3;    // `multi` is 3 in every SV model
+constexpr int CPL = 3;  // channels per lane
+
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void v2s_fwd_kernel(const float* __restrict__ v, const float* __restrict__ w, int64_t M, int C,
+                                                      float* __restrict__ s, float* __restrict__ z_out) {
+    const int g = threadIdx.x % G;
+    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) / G;
+    float wr[J][CPL];
+#pragma unroll
+    for (int t = 0; t < CPL; ++t) {
+        const int c = g + G * t;
+#pragma unroll
+        for (int j = 0; j < J; ++j) wr[j][t] = (c < C) ? w[j * C + c] : 0.f;
+    }
+    const int64_t iters = (M + ngroups - 1) / ngroups;  // uniform trip count: shuffles need every lane
+    for (int64_t it = 0; it < iters; ++it) {
+        const int64_t m = group + it * ngroups;
+        const bool live = m < M;
+        float x[3][CPL];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) {
+                const int c = g + G * t;
+                x[i][t] = (live && c < C) ? v[(m * 3 + i) * C + c] : 0.f;
+            }
+        float z[3][J];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                float p = 0.f;
+#pragma unroll
+                for (int t = 0; t < CPL; ++t) p = fmaf(x[i][t], wr[j][t], p);
+                z[i][j] = group_sum<G>(p);
+            }
+        if (live) {
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) {
+                const int c = g + G * t;
+                if (c < C) {
+#pragma unroll
+                    for (int j = 0; j < J; ++j)
+                        s[m * C * J + c * J + j] = x[0][t] * z[0][j] + x[1][t] * z[1][j] + x[2][t] * z[2][j];
+                }
+            }
+            if (z_out && g == 0) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < J; ++j) z_out[(m * 3 + i) * J + j] = z[i][j];
+            }
+        }
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void v2s_bwd_kernel(const float* __restrict__ v, const float* __restrict__ w,
+                                                      const float* __restrict__ ds, const float* __restrict__ dz_in, int64_t M,
+                                                      int C, float* __restrict__ dv, float* __restrict__ GX) {
+    __shared__ float gx_lds[J * 192];
+    const int g = threadIdx.x % G;
+    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) / G;
+    for (int e = threadIdx.x; e < J * C; e += blockDim.x) gx_lds[e] = 0.f;
+    __syncthreads();
+    float wr[J][CPL], gx[J][CPL];
+#pragma unroll
+    for (int t = 0; t < CPL; ++t) {
+        const int c = g + G * t;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            wr[j][t] = (c < C) ? w[j * C + c] : 0.f;
+            gx[j][t] = 0.f;
+        }
+    }
+    const int64_t iters = (M + ngroups - 1) / ngroups;
+    for (int64_t it = 0; it < iters; ++it) {
+        const int64_t m = group + it * ngroups;
+        const bool live = m < M;
+        float x[3][CPL], d[CPL][J];
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) {
+            const int c = g + G * t;
+            const bool ok = live && c < C;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) x[i][t] = ok ? v[(m * 3 + i) * C + c] : 0.f;
+#pragma unroll
+            for (int j = 0; j < J; ++j) d[t][j] = ok ? ds[m * C * J + c * J + j] : 0.f;
+        }
+        float z[3][J], dz[3][J];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                float pz = 0.f, pd = 0.f;
+#pragma unroll
+                for (int t = 0; t < CPL; ++t) {
+                    pz = fmaf(x[i][t], wr[j][t], pz);
+                    pd = fmaf(d[t][j], x[i][t], pd);
+                }
+                z[i][j] = group_sum<G>(pz);
+                dz[i][j] = group_sum<G>(pd) + ((live && dz_in) ? dz_in[(m * 3 + i) * J + j] : 0.f);
+            }
+        if (live) {
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) {
+                const int c = g + G * t;
+                if (c < C) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        float a = 0.f;
+#pragma unroll
+                        for (int j = 0; j < J; ++j) a += d[t][j] * z[i][j] + dz[i][j] * wr[j][t];
+                        dv[(m * 3 + i) * C + c] = a;
+                    }
+#pragma unroll
+                    for (int j = 0; j < J; ++j) gx[j][t] += dz[0][j] * x[0][t] + dz[1][j] * x[1][t] + dz[2][j] * x[2][t];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < CPL; ++t) {
+        const int c = g + G * t;
+        if (c < C) {
+#pragma unroll
+            for (int j = 0; j < J; ++j) atomicAdd(&gx_lds[j * C + c], gx[j][t]);
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < J * C; e += blockDim.x) atomicAdd(&GX[e], gx_lds[e]);
+}
+
+inline unsigned v2s_grid(int64_t M, int G) {
+    const int64_t groups_per_block = 256 / G;
+    int64_t blocks = svnet_cdiv(M, groups_per_block * 4);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+}  // namespace
+
+extern "C" int svnet_v2s_fwd_f32(const float* v, const float* w_eff, int64_t M, int64_t C, int64_t Jn, float* s, float* z_out,
+                                 void* stream) {
+    SVNET_REQUIRE(v && w_eff && s && M >= 0 && C > 0, SVNET_E_ARG, "svnet_v2s_fwd_f32: bad arguments");
+    SVNET_REQUIRE(Jn == J && C <= 192, SVNET_E_UNSUPPORTED, "svnet_v2s_fwd_f32: needs multi == 3 and C <= 192 (got %lld, %lld)",
+                  (long long)Jn, (long long)C);
+    if (M == 0) return SVNET_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (C <= 3) hipLaunchKernelGGL((v2s_fwd_kernel<1>), dim3(v2s_grid(M, 1)), dim3(256), 0, st, v, w_eff, M, (int)C, s, z_out);
+    else if (C <= 24) hipLaunchKernelGGL((v2s_fwd_kernel<8>), dim3(v2s_grid(M, 8)), dim3(256), 0, st, v, w_eff, M, (int)C, s, z_out);
+    else if (C <= 96) hipLaunchKernelGGL((v2s_fwd_kernel<32>), dim3(v2s_grid(M, 32)), dim3(256), 0, st, v, w_eff, M, (int)C, s, z_out);
+    else hipLaunchKernelGGL((v2s_fwd_kernel<64>), dim3(v2s_grid(M, 64)), dim3(256), 0, st, v, w_eff, M, (int)C, s, z_out);
+    SVNET_CHECK_LAUNCH("v2s_fwd_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_v2s_bwd_f32(const float* v, const float* w_eff, const float* ds, const float* dz_in, int64_t M, int64_t C,
+                                 int64_t Jn, float* dv, float* GX, void* stream) {
+    SVNET_REQUIRE(v && w_eff && ds && dv && GX && M >= 0 && C > 0, SVNET_E_ARG, "svnet_v2s_bwd_f32: bad arguments");
+    SVNET_REQUIRE(Jn == J && C <= 192, SVNET_E_UNSUPPORTED, "svnet_v2s_bwd_f32: needs multi == 3 and C <= 192 (got %lld, %lld)",
+                  (long long)Jn, (long long)C);
+    if (M == 0) return SVNET_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (C <= 3) hipLaunchKernelGGL((v2s_bwd_kernel<1>), dim3(v2s_grid(M, 1)), dim3(256), 0, st, v, w_eff, ds, dz_in, M, (int)C, dv, GX);
+    else if (C <= 24) hipLaunchKernelGGL((v2s_bwd_kernel<8>), dim3(v2s_grid(M, 8)), dim3(256), 0, st, v, w_eff, ds, dz_in, M, (int)C, dv, GX);
+    else if (C <= 96) hipLaunchKernelGGL((v2s_bwd_kernel<32>), dim3(v2s_grid(M, 32)), dim3(256), 0, st, v, w_eff, ds, dz_in, M, (int)C, dv, GX);
+    else hipLaunchKernelGGL((v2s_bwd_kernel<64>), dim3(v2s_grid(M, 64)), dim3(256), 0, st, v, w_eff, ds, dz_in, M, (int)C, dv, GX);
+    SVNET_CHECK_LAUNCH("v2s_bwd_kernel");
+    return SVNET_OK;
+}

@@ -1,0 +1,33 @@
+"""Data parallelism for the SV models: one process per GPU, one flat gradient bucket, one RCCL
+all-reduce per step over xGMI (backend "nccl" on ROCm); "gloo" on CPU for tests.
+
+The reference's only distribution mechanism is nn.DataParallel (main_cls_dgcnn.py:125): a mean loss over
+the gathered global batch with per-replica BatchNorm statistics.  The equivalent here is an average of
+the per-rank gradients and NO forward exchange (BN stays per rank).  The bucket is 6.2 MB for
+sv_dgcnn_cls: latency-bound, so it is sent as a single collective with every .grad a view into it.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradBucket:
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=dt, device=dev)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.mul_(1.0 / dist.get_world_size())

@@ -1,0 +1,6 @@
+"""`models` namespace of the SV family (the reference exports the same names from models/__init__.py:6-9)."""
+from .sv_dgcnn_cls import SV_DGCNN_CLS
+from .sv_dgcnn_partseg import SV_DGCNN_PSEG
+from .sv_pointnet_cls import SV_PointNet_CLS
+
+__all__ = ["SV_DGCNN_CLS", "SV_DGCNN_PSEG", "SV_PointNet_CLS"]

@@ -1,0 +1,50 @@
+"""SV-DGCNN classifier (caller of the hot path).
+
+Same constructor `(args, num_class)`, sub-module names and forward order as the reference
+models/sv_dgcnn_cls.py:22-82, so its state_dicts load unchanged; composition only — the arithmetic is
+in .sv_layers / .utils.sv_util (HIP kernels).
+"""
+from .sv_layers import *
+from .utils.sv_util import *
+from .sv_layers import batch_norm_act, _ACT_LEAKY
+from .. import _ops
+
+
+class SV_DGCNN_CLS(nn.Module):
+    def __init__(self, args, num_class=40):
+        super(SV_DGCNN_CLS, self).__init__()
+        self.k = args.k
+        self.binary = args.binary
+        drop = 0 if self.binary else 0.5
+        b = self.binary
+
+        self.init_scalar = Vector2Scalar(2, 3)
+        self.conv1 = SVBlock((6, 2), (32, 10))                       # never binarized (reference :30)
+        self.conv2 = SVBlock((64, 20), (32, 10), b)
+        self.conv3 = SVBlock((64, 20), (64, 21), b)
+        self.conv4 = SVBlock((128, 42), (128, 42), b)
+        self.conv5 = SVBlock((32 + 32 + 64 + 128, 10 + 10 + 21 + 42), (512, 170), b)
+        self.svfuse = SVFuse(170, 3, b)
+
+        self.linear1 = Linear((512 + 170 * 3) * 2, 512, bias=False, bw=b, ba=b)
+        self.bn1 = nn.BatchNorm1d(512)
+        self.dp1 = nn.Dropout(p=drop)
+        self.linear2 = Linear(512, 256, bias=False, bw=b, ba=b)
+        self.bn2 = nn.BatchNorm1d(256)
+        self.dp2 = nn.Dropout(p=drop)
+        self.linear3 = nn.Linear(256, num_class)
+
+    def forward(self, x):
+        v = get_graph_feature(x.unsqueeze(1), k=self.k)               # [B,N,k,3,2]
+        level = svpool(self.conv1((self.init_scalar(v), v)))
+        pyramid = [level]
+        for block in (self.conv2, self.conv3, self.conv4):             # dynamic feature-space graph per level
+            level = svpool(block(get_graph_feature_sv(level, k=self.k)))
+            pyramid.append(level)
+
+        feat = self.svfuse(self.conv5(svcat(pyramid)))                 # [B,N,1022]
+        pooled = torch.cat((_ops.Pool.apply(feat, 1, 0), _ops.Pool.apply(feat, 1, 1)), dim=1)   # max | mean over points
+
+        h = self.dp1(batch_norm_act(self.bn1, self.linear1(pooled), _ACT_LEAKY, 0.2))
+        h = self.dp2(batch_norm_act(self.bn2, self.linear2(h), _ACT_LEAKY, 0.2))
+        return _ops.FpLinear.apply(h, self.linear3.weight, self.linear3.bias)

@@ -1,0 +1,88 @@
+"""SV-DGCNN part segmentation (caller of the hot path).
+
+Same constructor `(args, num_part)`, channel rounding, sub-module names and forward order as the
+reference models/sv_dgcnn_partseg.py:18-128; composition only.
+"""
+from .sv_layers import *
+from .utils.sv_util import *
+from .sv_layers import batch_norm_act, _ACT_LEAKY
+from .. import _ops
+
+
+def _round8(v, divisor=8):
+    """Channel counts rounded to a multiple of 8, never more than 10 % below v (reference :18-31)."""
+    r = max(divisor, int(v + divisor / 2) // divisor * divisor)
+    return r + divisor if r < 0.9 * v else r
+
+
+_V = _round8
+
+
+class _ConvBNAct(nn.Sequential):
+    """[conv, BatchNorm1d, LeakyReLU] on channel-first rows; keys `.0.*`, `.1.*` as in the reference's nn.Sequential."""
+
+    def forward(self, x):                                            # x: [B,C,N]
+        y = self[0](x) if isinstance(self[0], Conv1d) else \
+            _ops.FpLinear.apply(x.transpose(1, 2), self[0].weight.view(self[0].out_channels, -1), None).transpose(1, 2)
+        rows = batch_norm_act(self[1], y.transpose(1, 2), _ACT_LEAKY, 0.2)
+        return rows.transpose(1, 2).contiguous()
+
+
+class SV_DGCNN_PSEG(nn.Module):
+    def __init__(self, args, num_part):
+        super(SV_DGCNN_PSEG, self).__init__()
+        self.args = args
+        self.k = args.k
+        self.binary = args.binary
+        self.dropout = 0 if self.binary else args.dropout
+        self.emb = 1024
+        b, emb = self.binary, self.emb
+        s1, v1 = _V(64 // 2), _V(64 // 6)
+        s3, v3 = _V(128 // 2), _V(128 // 6)
+        s4, v4 = _V(256 // 2), _V(256 // 6)
+        cs, cv = s1 * 2 + s3 + s4, v1 * 2 + v3 + v4
+
+        self.init_scalar = Vector2Scalar(2, 3)
+        self.conv1 = SVBlock((6, 2), (s1, v1))
+        self.conv2 = SVBlock((s1 * 2, v1 * 2), (s1, v1), b)
+        self.conv3 = SVBlock((s1 * 2, v1 * 2), (s3, v3), b)
+        self.conv4 = SVBlock((s3 * 2, v3 * 2), (s4, v4), b)
+
+        self.svfuse1 = SVFuse(cv, 3, b)
+        self.conv5 = SVBlock((cs, cv), (_V(emb // 2), _V(emb // 6)), b)
+        self.conv6 = SVBlock((_V(emb // 2), _V(emb // 6)), (_V(emb // 4), _V(emb // 12)), b)
+        self.svfuse2 = SVFuse(_V(emb // 12), 3, b)
+        self.svfuse3 = SVFuse(_V(emb // 6), 3, b)
+        self.conv7 = _ConvBNAct(nn.Conv1d(16, 64, kernel_size=1, bias=False), nn.BatchNorm1d(64),
+                                nn.LeakyReLU(negative_slope=0.2))
+        head_in = _V(emb // 2) + _V(emb // 4) + (_V(emb // 6) + _V(emb // 12)) * 3 + 64 + cs + cv * 3
+        self.conv8 = _ConvBNAct(Conv1d(head_in, 256, b), nn.BatchNorm1d(256), nn.LeakyReLU(negative_slope=0.2))
+        self.dp1 = nn.Dropout(p=self.dropout)
+        self.conv9 = _ConvBNAct(Conv1d(256, 256, b), nn.BatchNorm1d(256), nn.LeakyReLU(negative_slope=0.2))
+        self.dp2 = nn.Dropout(p=self.dropout)
+        self.conv10 = _ConvBNAct(Conv1d(256, 128, b), nn.BatchNorm1d(128), nn.LeakyReLU(negative_slope=0.2))
+        self.conv11 = nn.Conv1d(128, num_part, kernel_size=1, bias=False)
+
+    def forward(self, x, l):
+        B, N = x.size(0), x.size(2)
+        v = get_graph_feature(x.unsqueeze(1), k=self.k)
+        level = svpool(self.conv1((self.init_scalar(v), v)))
+        pyramid = [level]
+        for block in (self.conv2, self.conv3, self.conv4):
+            level = svpool(block(get_graph_feature_sv(level, k=self.k)))
+            pyramid.append(level)
+
+        x = svcat(pyramid)
+        fine = self.svfuse1(x)                                        # [B,N,cs+3cv]
+        x = self.conv5(x)
+        pooled = self.svfuse2(self.conv6(svpool(x, dim=1, keepdim=True)))          # [B,1,emb/2]
+        glob = _ops.Pool.apply(self.svfuse3(x), 1, 0).unsqueeze(-1)                 # max over points -> [B,emb,1]
+
+        lab = self.conv7(l.view(B, -1, 1))                            # [B,64,1]
+        x = torch.cat([glob, pooled.transpose(-1, -2), lab], dim=1).repeat(1, 1, N)
+        x = torch.cat([x, fine.transpose(-1, -2)], dim=1)            # [B,head_in,N]
+        x = self.dp1(self.conv8(x))
+        x = self.dp2(self.conv9(x))
+        x = self.conv10(x)
+        w = self.conv11.weight.view(self.conv11.out_channels, -1)
+        return _ops.FpLinear.apply(x.transpose(1, 2), w, None).transpose(1, 2).contiguous()

@@ -1,0 +1,218 @@
+"""Scalar/vector layer library of SVNet on MI355X.
+
+Drop-in for the reference module `models/sv_layers.py`: same class names, constructor signatures,
+sub-module / parameter names (state_dict compatible) and train/eval behaviour:
+  Linear :20-53, Conv1d :55-78, VectorBN :81-102, Vector2Scalar :104-129, VectorReLU :131-149,
+  SVBlock :151-196, SVFuse :198-220, SV_STNkd :222-244.
+Every forward runs hand-written gfx950 kernels through svnet_amd._ops; tensors must be on a HIP
+device (no CPU fallback).
+"""
+import os
+import sys
+import copy
+import math
+import numpy as np
+
+import torch
+import torch.nn as nn
+import torch.nn.init as init
+import torch.nn.functional as F
+
+from .. import _ops
+from .utils.sv_util import svpool
+
+EPS = 1e-6
+
+__all__ = ["EPS", "Linear", "Conv1d", "VectorBN", "Vector2Scalar", "VectorReLU", "SVBlock", "SVFuse", "SV_STNkd",
+           "svpool", "torch", "nn", "F", "np", "math", "os", "sys", "copy", "init"]
+
+_ACT_NONE, _ACT_LEAKY, _ACT_RELU = 0, 1, 2
+
+
+def batch_norm_act(bn, x, act=_ACT_NONE, slope=0.2):
+    """nn.BatchNorm1d `bn` (+ activation) over the rows of x [..., C] in one fused pass."""
+    training = bn.training or bn.running_mean is None
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _ops.BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, act, slope)
+
+
+class Linear(nn.Linear):
+    """nn.Linear whose weights (bw) and/or activations (ba) are binarized with sign():
+    y = (sign(x + beta) . sign(W)^T) * scale (+ bias).  sign(0) = 0, so operands are ternary;
+    the backward is the clamp(-1.2, 1.2) straight-through estimator in both modes."""
+
+    def __init__(self, in_channels, out_channels, bias, bw=False, ba=False):
+        super(Linear, self).__init__(in_channels, out_channels, bias)
+        self.bw, self.ba = bw, ba
+        if ba:
+            self.beta = nn.Parameter(torch.zeros(1, in_channels))
+        if bw:
+            self.scale = nn.Parameter(torch.ones(1, out_channels) / math.sqrt(in_channels))
+
+    def forward(self, x):
+        if self.bw and self.ba:
+            return _ops.BinLinear.apply(x, self.weight, self.beta, self.scale, self.bias)
+        if self.bw:
+            y = _ops.BwLinear.apply(x, self.weight, self.scale)
+            return y if self.bias is None else y + self.bias
+        if self.ba:
+            raise AttributeError("'Linear' object has no attribute 'scale'")  # same failure as the reference (:49)
+        return _ops.FpLinear.apply(x, self.weight, self.bias)
+
+
+class Conv1d(nn.Conv1d):
+    """1x1 convolution on channel-first [B,C,N] rows, optionally binarized like Linear(bw, ba)."""
+
+    def __init__(self, in_channels, out_channels, binary=False):
+        super(Conv1d, self).__init__(in_channels, out_channels, 1, bias=False)
+        print('Conv1d: ', in_channels, out_channels)
+        self.binary = binary
+        if binary:
+            self.beta = nn.Parameter(torch.zeros(1, in_channels, 1))
+            self.scale = nn.Parameter(torch.ones(1, out_channels, 1) / math.sqrt(in_channels))
+
+    def forward(self, x):
+        rows = x.transpose(1, 2)                                   # [B,N,C] view; made contiguous by the op
+        w2 = self.weight.view(self.out_channels, self.in_channels)
+        if self.binary:
+            y = _ops.BinLinear.apply(rows, w2, self.beta.view(1, -1), self.scale.view(1, -1), None)
+        else:
+            y = _ops.FpLinear.apply(rows, w2, None)
+        return y.transpose(1, 2).contiguous()
+
+
+class VectorBN(nn.Module):
+    """Batch-normalise the length of each vector channel: v * BN(|v| + EPS) / (|v| + EPS)."""
+
+    def __init__(self, dim):
+        super(VectorBN, self).__init__()
+        self.bn = nn.BatchNorm1d(dim)
+
+    def forward(self, v, gate=None):
+        '''
+        shape of v: B, N_points, [k,] 3, dim ; gate (optional): B, dim
+        '''
+        bn = self.bn
+        training = bn.training or bn.running_mean is None
+        if bn.training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        rows = v.numel() // (3 * v.shape[-1])
+        rows_per_batch = max(rows // v.shape[0], 1)
+        return _ops.VBN.apply(v, bn.weight, bn.bias, bn.running_mean, bn.running_var, gate, rows_per_batch, training)
+
+
+class Vector2Scalar(nn.Module):
+    """Rotation-invariant scalars s[d*multi+j] = sum_i v[i,d] * (v W^T)[i,j]."""
+
+    def __init__(self, v_dim, multi, binary=False, trans_back=False):
+        super(Vector2Scalar, self).__init__()
+        self.trans_back = trans_back
+        self.linear = Linear(v_dim, multi, bias=False, bw=binary)
+
+    def forward(self, v):
+        '''
+        shape of v: B, N_points, [k,] 3, dim
+        '''
+        assert v.ndim in [3, 4, 5], 'dim of v should be in [4, 5], got {}'.format(v.ndim)
+        s, z = _ops.V2S.apply(v, self.linear.weight, self.linear.scale if self.linear.bw else None)
+        return (s, z) if self.trans_back else s
+
+
+class VectorReLU(nn.Module):
+    """Keeps the vectors whose norm exceeds the (n/10)-th smallest norm of their sample.  Never instantiated
+    by any SV model (API surface only): a thin composition of torch ops on the device, no dedicated kernel."""
+
+    def __init__(self):
+        super(VectorReLU, self).__init__()
+        self.div = 10
+
+    def forward(self, x):
+        shape_x = x.shape
+        rows = x.reshape(shape_x[0], -1, 3, shape_x[-1])
+        kth = rows.shape[1] // self.div
+        length = torch.linalg.vector_norm(rows, dim=2, keepdim=True).detach()
+        threshold = torch.kthvalue(length, kth, dim=1, keepdim=True)[0]
+        return torch.where(length > threshold, rows, torch.zeros_like(rows)).view(shape_x)
+
+
+class SVBlock(nn.Module):
+    """One scalar/vector layer: gate from the mean scalar, invariant scalars from the vectors, (binarized)
+    scalar linear + BN + LeakyReLU, (sign-weight) vector linear + VectorBN, vectors scaled by the gate."""
+
+    def __init__(self, in_dims, out_dims, binary=False):
+        super(SVBlock, self).__init__()
+        print('SVBlock: ', in_dims, out_dims)
+
+        self.gate = nn.Sequential(
+            nn.Linear(in_dims[0], out_dims[1] // 2, bias=False),
+            nn.ReLU(inplace=True),
+            nn.Linear(out_dims[1] // 2, out_dims[1], bias=False),
+            nn.Sigmoid(),
+        )
+        self.v2s = Vector2Scalar(in_dims[1], 3, binary=binary)
+
+        self.linear1 = Linear(in_dims[0] + in_dims[1] * 3, out_dims[0], bias=False, bw=binary, ba=binary)
+        self.bn1 = nn.BatchNorm1d(out_dims[0])
+        self.relu = nn.LeakyReLU(negative_slope=0.2)
+
+        self.linear2 = Linear(in_dims[1], out_dims[1], bias=False, bw=binary)
+        self.bn2 = VectorBN(out_dims[1])
+
+    def _gate(self, s):
+        pooled = _ops.Pool.apply(s.reshape(s.shape[0], -1, s.shape[-1]), 1, 1)          # mean over all rows of a cloud
+        h = _ops.Act.apply(_ops.FpLinear.apply(pooled, self.gate[0].weight, None), 1)   # ReLU
+        return _ops.Act.apply(_ops.FpLinear.apply(h, self.gate[2].weight, None), 2)     # Sigmoid -> [B, Cv_out]
+
+    def forward(self, x):
+        '''
+        shape of s: B, N_points, [k,] s_dim
+        shape of v: B, N_points, [k,] 3, v_dim
+        '''
+        s, v = x
+        v_scale = self._gate(s)
+
+        s = torch.cat([s, self.v2s(v)], dim=-1)
+        s = self.linear1(s)
+        s = batch_norm_act(self.bn1, s, _ACT_LEAKY, self.relu.negative_slope)
+
+        v = self.linear2(v)
+        v = self.bn2(v, gate=v_scale)
+        return (s, v)
+
+
+class SVFuse(nn.Module):
+    """cat[s, Vector2Scalar(v)] (optionally also returning the 3 x multi frame z)."""
+
+    def __init__(self, v_dim, multi, binary, trans_back=False):
+        super(SVFuse, self).__init__()
+        print('SVFuse: ', v_dim)
+        self.trans_back = trans_back
+        self.v2s = Vector2Scalar(v_dim, multi, binary=binary, trans_back=trans_back)
+
+    def forward(self, x):
+        s, v = x
+        if self.trans_back:
+            s_v, trans = self.v2s(v)
+            return torch.cat([s, s_v], dim=-1), trans
+        return torch.cat([s, self.v2s(v)], dim=-1)
+
+
+class SV_STNkd(nn.Module):
+    """Three per-point SVBlocks, pooling over the points, three per-cloud SVBlocks."""
+
+    def __init__(self, dim, binary):
+        super(SV_STNkd, self).__init__()
+        widths = [dim, (64 // 2, 64 // 6), (128 // 2, 128 // 6), (1024 // 2, 1024 // 6),
+                  (512 // 2, 512 // 6), (256 // 2, 256 // 6), dim]
+        names = ['conv1', 'conv2', 'conv3', 'fc1', 'fc2', 'fc3']
+        for i, name in enumerate(names):
+            setattr(self, name, SVBlock(widths[i], widths[i + 1], binary=binary))
+
+    def forward(self, x):
+        for name in ('conv1', 'conv2', 'conv3'):
+            x = getattr(self, name)(x)
+        x = svpool(x, dim=1)
+        for name in ('fc1', 'fc2', 'fc3'):
+            x = getattr(self, name)(x)
+        return x

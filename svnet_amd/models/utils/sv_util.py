@@ -1,0 +1,87 @@
+"""Graph / pooling utilities of the SV models on MI355X.
+
+Drop-in for the reference module `models/utils/sv_util.py` (same function names, arguments and
+defaults: knn :19, get_graph_feature :28, get_graph_feature_cross :64, get_graph_feature_sv :90,
+svpool :118, svcat :134).  Arithmetic runs in libsvnet_hip.so; tensors must live on a HIP device.
+"""
+import os
+import sys
+import copy
+import math
+import numpy as np
+
+import torch
+import torch.nn as nn
+import torch.nn.init as init
+import torch.nn.functional as F
+
+from ... import _ops
+
+__all__ = ["knn", "get_graph_feature", "get_graph_feature_cross", "get_graph_feature_sv", "svpool", "svcat",
+           "torch", "nn", "F", "np", "math", "os", "sys", "copy", "init"]
+
+
+def knn(x, k):
+    """x: [B,C,N] -> [B,N,k] int64 neighbour ids (cloud-local, nearest first, self at slot 0).
+    Bit-exact with the reference's topk of -|x_i-x_j|^2 (ties: lowest id first)."""
+    return _ops.knn(x, k)
+
+
+def _xyz_edges(x, k, idx, x_coord, mode):
+    if x.requires_grad:
+        raise NotImplementedError("get_graph_feature[_cross]: gradients w.r.t. the input coordinates are not on the "
+                                  "hot path (no SV model needs them)")
+    B, N = x.size(0), x.size(3)
+    pts = x.reshape(B, -1, N)
+    if idx is None:
+        src = pts if x_coord is None else x_coord.reshape(B, -1, N)
+        idx = _ops.knn(src, k)
+    return _ops.edge_xyz(pts, idx, mode)
+
+
+def get_graph_feature(x, k=20, idx=None, x_coord=None, first=False):
+    """x: [B,1,3m,N] -> [B,N,k,3,2m]: channel block 0 = x_j - x_i, block 1 = x_i
+    (first=True: block 1 = mean over the k neighbours of x_j - x_i)."""
+    return _xyz_edges(x, k, idx, x_coord, 1 if first else 0)
+
+
+def get_graph_feature_cross(x, k=20, idx=None):
+    """x: [B,1,3m,N] -> [B,N,k,3,3m]: (x_j - x_i, x_i, x_j x x_i)."""
+    return _xyz_edges(x, k, idx, None, 2)
+
+
+def get_graph_feature_sv(x, k=20, idx=None):
+    """(s [B,N,Cs], v [B,N,3,Cv]) -> (s_e [B,N,k,2Cs], v_e [B,N,k,3,2Cv]) on the feature-space k-NN graph of
+    cat[s, v.flat].  A caller-supplied idx holds GLOBAL row ids b*N+j, as in the reference (:99-111)."""
+    s, v = x
+    B, N, Cs = s.shape
+    Cv = v.size(-1)
+    is_global = idx is not None
+    if idx is None:
+        feat = torch.cat([s.detach(), v.detach().reshape(B, N, 3 * Cv)], dim=-1)
+        idx = _ops.knn(feat.transpose(-1, -2), k)
+    else:
+        idx = idx.reshape(B, N, k)
+    s_e = _ops.EdgeDiffcat.apply(s.reshape(B, N, 1, Cs), idx, is_global, k).view(B, N, k, 2 * Cs)
+    v_e = _ops.EdgeDiffcat.apply(v, idx, is_global, k)
+    return (s_e, v_e)
+
+
+def svpool(x, dim=2, keepdim=False, spool='max'):
+    """s: max (or mean) over `dim`; v: mean over `dim`.  Max ties send the gradient to the first index."""
+    s, v = x
+    if spool == 'max':
+        s = _ops.Pool.apply(s, dim, 0)
+    elif spool == 'mean':
+        s = _ops.Pool.apply(s, dim, 1)
+    else:
+        raise ValueError('not recognized pooling mean {}'.format(spool))
+    v = _ops.Pool.apply(v, dim, 1)
+    if keepdim:
+        s, v = s.unsqueeze(dim), v.unsqueeze(dim)
+    return (s, v)
+
+
+def svcat(xlist):
+    """Concatenate the scalar parts and the vector parts along the channel axis (pure data movement)."""
+    return (torch.cat([x[0] for x in xlist], dim=-1), torch.cat([x[1] for x in xlist], dim=-1))

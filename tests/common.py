@@ -1,0 +1,40 @@
+"""Shared comparison helpers for the parity tests."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_npz(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def _kind(key):
+    for p in ("out", "dx", "d:", "buf:"):
+        if key.startswith(p):
+            return p
+    return "other"
+
+
+def compare_case(got, ref, rtol, name=""):
+    """Every key of `ref` must be matched by `got` within rtol * max(|ref[key]|max, 1e-2 * largest |.|max among the
+    keys of the same kind).  The second term is the noise floor for gradients that are mathematically ~0 (e.g. the
+    scale of a linear that feeds a train-mode BatchNorm)."""
+    groups = {}
+    for k, v in ref.items():
+        groups[_kind(k)] = max(groups.get(_kind(k), 0.0), float(np.abs(v).max()) if v.size else 0.0)
+    worst = (0.0, None)
+    for k, r in ref.items():
+        assert k in got, "%s: missing key %s" % (name, k)
+        g = np.asarray(got[k], dtype=np.float64)
+        r = np.asarray(r, dtype=np.float64)
+        assert g.shape == r.shape, "%s/%s: shape %s vs %s" % (name, k, g.shape, r.shape)
+        if r.size == 0:
+            continue
+        scale = max(float(np.abs(r).max()), 1e-2 * groups[_kind(k)], 1e-30)
+        err = float(np.abs(g - r).max()) / scale
+        if err > worst[0]:
+            worst = (err, k)
+        assert err <= rtol, "%s/%s: rel err %.3e > %.1e (scale %.3e)" % (name, k, err, rtol, scale)
+    return worst
