@@ -161,13 +161,13 @@ class BwLinear(torch.autograd.Function):
     """y = (x sign(W)^T) * scale with fp32 activations (sv_layers.py:44-49 with bw only: linear2, v2s.linear, svfuse)."""
 
     @staticmethod
-    def forward(ctx, x, W, scale):
+    def forward(ctx, x, W, scale, training=True):
         _hip(x, W, scale)
+        ctx.training = bool(training)
         x2 = _f32c(x).reshape(-1, x.shape[-1])
         W = _f32c(W)
         M, K = x2.shape
         O = W.shape[0]
-        L = _lib.lib()
         w_b = torch.empty((O, K), dtype=torch.float32, device=x.device)
         w_eff = torch.empty((O, K), dtype=torch.float32, device=x.device)
         sc = _f32c(scale).view(-1)
@@ -194,17 +194,19 @@ class BwLinear(torch.autograd.Function):
             gemm(O, K, M, A=g2, a_rs=1, a_cs=O, B=x2, b_rs=K, b_cs=1, C=GX, ldc=K)
             dW = torch.zeros((O, K), dtype=torch.float32, device=g.device)
             dsc = torch.zeros((O,), dtype=torch.float32, device=g.device)
-            call("svnet_binweight_grad_f32", _p(GX), _p(W), _p(sc), O, K, _p(dW), _p(dsc), _stream())
+            # eval mode binarizes with a bare sign(): no straight-through gradient reaches W (sv_layers.py:44-45)
+            call("svnet_binweight_grad_f32", _p(GX), _p(W), _p(sc), O, K, _p(dW) if ctx.training else None, _p(dsc), _stream())
             dsc = dsc.view(ctx.sshape)
-        return dx, dW, dsc
+        return dx, dW, dsc, None
 
 
 class BinLinear(torch.autograd.Function):
     """y = (sign(x+beta) sign(W)^T) * scale (+ b): ternary XNOR/popcount (sv_layers.py:35-51 with bw and ba)."""
 
     @staticmethod
-    def forward(ctx, x, W, beta, scale, bias):
+    def forward(ctx, x, W, beta, scale, bias, training=True):
         _hip(x, W, beta, scale, bias)
+        ctx.training = bool(training)
         x2 = _f32c(x).reshape(-1, x.shape[-1])
         W = _f32c(W)
         M, K = x2.shape
@@ -236,9 +238,12 @@ class BinLinear(torch.autograd.Function):
         g2 = _f32c(g).reshape(M, O)
         dx = dW = dbeta = dsc = dbias = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
-            dx = torch.empty((M, K), dtype=torch.float32, device=dev)
             dbeta = torch.zeros((K,), dtype=torch.float32, device=dev)
-            gemm(M, K, O, A=g2, a_rs=O, a_cs=1, B=w_eff, b_rs=K, b_cs=1, C=dx, ldc=K, mask=(x_ste, KW), col_sum=dbeta)
+            if ctx.training:
+                dx = torch.empty((M, K), dtype=torch.float32, device=dev)
+                gemm(M, K, O, A=g2, a_rs=O, a_cs=1, B=w_eff, b_rs=K, b_cs=1, C=dx, ldc=K, mask=(x_ste, KW), col_sum=dbeta)
+            else:   # eval: bare sign() has zero gradient (sv_layers.py:38-39)
+                dx = torch.zeros((M, K), dtype=torch.float32, device=dev)
             dx = dx.view(xshape)
             dbeta = dbeta.view(bshape)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[3]:
@@ -247,11 +252,11 @@ class BinLinear(torch.autograd.Function):
             gemm(K, O, M, a_planes=(x_sign, x_nz, KW, True), B=g2, b_rs=O, b_cs=1, C=GX, ldc=1, c_cs=K)
             dW = torch.zeros((O, K), dtype=torch.float32, device=dev)
             dsc = torch.zeros((O,), dtype=torch.float32, device=dev)
-            call("svnet_binweight_grad_f32", _p(GX), _p(W), _p(sc), O, K, _p(dW), _p(dsc), _stream())
+            call("svnet_binweight_grad_f32", _p(GX), _p(W), _p(sc), O, K, _p(dW) if ctx.training else None, _p(dsc), _stream())
             dsc = dsc.view(sshape)
         if has_bias and ctx.needs_input_grad[4]:
             dbias = pool_raw(g2, 1, M, O, 1)[0].view(O) * float(M)
-        return dx, dW, dbeta, dsc, dbias
+        return dx, dW, dbeta, dsc, dbias, None
 
 
 # ----------------------------------------------------------------------------- Vector2Scalar
@@ -260,8 +265,9 @@ class V2S(torch.autograd.Function):
     """Vector2Scalar (sv_layers.py:111-129). Returns (s [...,C*J], z [...,3,J])."""
 
     @staticmethod
-    def forward(ctx, v, W, scale):
+    def forward(ctx, v, W, scale, training=True):
         _hip(v, W, scale)
+        ctx.training = bool(training)
         ctx.set_materialize_grads(False)
         v3 = _f32c(v).reshape(-1, 3, v.shape[-1])
         W = _f32c(W)
@@ -298,9 +304,9 @@ class V2S(torch.autograd.Function):
         if sc is not None:
             dW = torch.zeros((J, C), dtype=torch.float32, device=v3.device)
             dsc = torch.zeros((J,), dtype=torch.float32, device=v3.device)
-            call("svnet_binweight_grad_f32", _p(GX), _p(W), _p(sc), J, C, _p(dW), _p(dsc), _stream())
+            call("svnet_binweight_grad_f32", _p(GX), _p(W), _p(sc), J, C, _p(dW) if ctx.training else None, _p(dsc), _stream())
             dsc = dsc.view(ctx.sshape)
-        return dv.view(ctx.vshape), dW, dsc
+        return dv.view(ctx.vshape), dW, dsc, None
 
 
 # ----------------------------------------------------------------------------- normalisation

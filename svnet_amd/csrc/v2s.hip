@@ -11,7 +11,7 @@
 namespace {
 
 constexpr int J = 3;    // `multi` is 3 in every SV model
-constexpr int CPL = 3;  // channels per lane
+// CPL (template): channels per lane, 3 for C <= 192, 6 for C <= 384 (PointNet conv_fuse: Cv = 340)
 
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
@@ -20,7 +20,7 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
-template <int G>
+template <int G, int CPL>
 __global__ __launch_bounds__(256) void v2s_fwd_kernel(const float* __restrict__ v, const float* __restrict__ w, int64_t M, int C,
                                                       float* __restrict__ s, float* __restrict__ z_out) {
     const int g = threadIdx.x % G;
@@ -75,11 +75,11 @@ __global__ __launch_bounds__(256) void v2s_fwd_kernel(const float* __restrict__ 
     }
 }
 
-template <int G>
+template <int G, int CPL>
 __global__ __launch_bounds__(256) void v2s_bwd_kernel(const float* __restrict__ v, const float* __restrict__ w,
                                                       const float* __restrict__ ds, const float* __restrict__ dz_in, int64_t M,
                                                       int C, float* __restrict__ dv, float* __restrict__ GX) {
-    __shared__ float gx_lds[J * 192];
+    __shared__ float gx_lds[J * 384];
     const int g = threadIdx.x % G;
     const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) / G;
@@ -166,14 +166,17 @@ inline unsigned v2s_grid(int64_t M, int G) {
 extern "C" int svnet_v2s_fwd_f32(const float* v, const float* w_eff, int64_t M, int64_t C, int64_t Jn, float* s, float* z_out,
                                  void* stream) {
     SVNET_REQUIRE(v && w_eff && s && M >= 0 && C > 0, SVNET_E_ARG, "svnet_v2s_fwd_f32: bad arguments");
-    SVNET_REQUIRE(Jn == J && C <= 192, SVNET_E_UNSUPPORTED, "svnet_v2s_fwd_f32: needs multi == 3 and C <= 192 (got %lld, %lld)",
+    SVNET_REQUIRE(Jn == J && C <= 384, SVNET_E_UNSUPPORTED, "svnet_v2s_fwd_f32: needs multi == 3 and C <= 384 (got %lld, %lld)",
                   (long long)Jn, (long long)C);
     if (M == 0) return SVNET_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (C <= 3) hipLaunchKernelGGL((v2s_fwd_kernel<1>), dim3(v2s_grid(M, 1)), dim3(256), 0, st, v, w_eff, M, (int)C, s, z_out);
-    else if (C <= 24) hipLaunchKernelGGL((v2s_fwd_kernel<8>), dim3(v2s_grid(M, 8)), dim3(256), 0, st, v, w_eff, M, (int)C, s, z_out);
-    else if (C <= 96) hipLaunchKernelGGL((v2s_fwd_kernel<32>), dim3(v2s_grid(M, 32)), dim3(256), 0, st, v, w_eff, M, (int)C, s, z_out);
-    else hipLaunchKernelGGL((v2s_fwd_kernel<64>), dim3(v2s_grid(M, 64)), dim3(256), 0, st, v, w_eff, M, (int)C, s, z_out);
+#define SVNET_V2S(G, CPL) hipLaunchKernelGGL((v2s_fwd_kernel<G, CPL>), dim3(v2s_grid(M, G)), dim3(256), 0, st, v, w_eff, M, (int)C, s, z_out)
+    if (C <= 3) SVNET_V2S(1, 3);
+    else if (C <= 24) SVNET_V2S(8, 3);
+    else if (C <= 96) SVNET_V2S(32, 3);
+    else if (C <= 192) SVNET_V2S(64, 3);
+    else SVNET_V2S(64, 6);
+#undef SVNET_V2S
     SVNET_CHECK_LAUNCH("v2s_fwd_kernel");
     return SVNET_OK;
 }
@@ -181,14 +184,17 @@ extern "C" int svnet_v2s_fwd_f32(const float* v, const float* w_eff, int64_t M, 
 extern "C" int svnet_v2s_bwd_f32(const float* v, const float* w_eff, const float* ds, const float* dz_in, int64_t M, int64_t C,
                                  int64_t Jn, float* dv, float* GX, void* stream) {
     SVNET_REQUIRE(v && w_eff && ds && dv && GX && M >= 0 && C > 0, SVNET_E_ARG, "svnet_v2s_bwd_f32: bad arguments");
-    SVNET_REQUIRE(Jn == J && C <= 192, SVNET_E_UNSUPPORTED, "svnet_v2s_bwd_f32: needs multi == 3 and C <= 192 (got %lld, %lld)",
+    SVNET_REQUIRE(Jn == J && C <= 384, SVNET_E_UNSUPPORTED, "svnet_v2s_bwd_f32: needs multi == 3 and C <= 384 (got %lld, %lld)",
                   (long long)Jn, (long long)C);
     if (M == 0) return SVNET_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (C <= 3) hipLaunchKernelGGL((v2s_bwd_kernel<1>), dim3(v2s_grid(M, 1)), dim3(256), 0, st, v, w_eff, ds, dz_in, M, (int)C, dv, GX);
-    else if (C <= 24) hipLaunchKernelGGL((v2s_bwd_kernel<8>), dim3(v2s_grid(M, 8)), dim3(256), 0, st, v, w_eff, ds, dz_in, M, (int)C, dv, GX);
-    else if (C <= 96) hipLaunchKernelGGL((v2s_bwd_kernel<32>), dim3(v2s_grid(M, 32)), dim3(256), 0, st, v, w_eff, ds, dz_in, M, (int)C, dv, GX);
-    else hipLaunchKernelGGL((v2s_bwd_kernel<64>), dim3(v2s_grid(M, 64)), dim3(256), 0, st, v, w_eff, ds, dz_in, M, (int)C, dv, GX);
+#define SVNET_V2S(G, CPL) hipLaunchKernelGGL((v2s_bwd_kernel<G, CPL>), dim3(v2s_grid(M, G)), dim3(256), 0, st, v, w_eff, ds, dz_in, M, (int)C, dv, GX)
+    if (C <= 3) SVNET_V2S(1, 3);
+    else if (C <= 24) SVNET_V2S(8, 3);
+    else if (C <= 96) SVNET_V2S(32, 3);
+    else if (C <= 192) SVNET_V2S(64, 3);
+    else SVNET_V2S(64, 6);
+#undef SVNET_V2S
     SVNET_CHECK_LAUNCH("v2s_bwd_kernel");
     return SVNET_OK;
 }

@@ -39,8 +39,9 @@ def batch_norm_act(bn, x, act=_ACT_NONE, slope=0.2):
 
 class Linear(nn.Linear):
     """nn.Linear whose weights (bw) and/or activations (ba) are binarized with sign():
-    y = (sign(x + beta) . sign(W)^T) * scale (+ bias).  sign(0) = 0, so operands are ternary;
-    the backward is the clamp(-1.2, 1.2) straight-through estimator in both modes."""
+    y = (sign(x + beta) . sign(W)^T) * scale (+ bias).  sign(0) = 0, so operands are ternary.
+    train(): backward is the clamp(-1.2, 1.2) straight-through estimator; eval(): bare sign(), whose
+    gradient is zero (only `scale` and `bias` receive one), exactly as in the reference."""
 
     def __init__(self, in_channels, out_channels, bias, bw=False, ba=False):
         super(Linear, self).__init__(in_channels, out_channels, bias)
@@ -52,9 +53,9 @@ class Linear(nn.Linear):
 
     def forward(self, x):
         if self.bw and self.ba:
-            return _ops.BinLinear.apply(x, self.weight, self.beta, self.scale, self.bias)
+            return _ops.BinLinear.apply(x, self.weight, self.beta, self.scale, self.bias, self.training)
         if self.bw:
-            y = _ops.BwLinear.apply(x, self.weight, self.scale)
+            y = _ops.BwLinear.apply(x, self.weight, self.scale, self.training)
             return y if self.bias is None else y + self.bias
         if self.ba:
             raise AttributeError("'Linear' object has no attribute 'scale'")  # same failure as the reference (:49)
@@ -76,7 +77,7 @@ class Conv1d(nn.Conv1d):
         rows = x.transpose(1, 2)                                   # [B,N,C] view; made contiguous by the op
         w2 = self.weight.view(self.out_channels, self.in_channels)
         if self.binary:
-            y = _ops.BinLinear.apply(rows, w2, self.beta.view(1, -1), self.scale.view(1, -1), None)
+            y = _ops.BinLinear.apply(rows, w2, self.beta.view(1, -1), self.scale.view(1, -1), None, self.training)
         else:
             y = _ops.FpLinear.apply(rows, w2, None)
         return y.transpose(1, 2).contiguous()
@@ -115,7 +116,7 @@ class Vector2Scalar(nn.Module):
         shape of v: B, N_points, [k,] 3, dim
         '''
         assert v.ndim in [3, 4, 5], 'dim of v should be in [4, 5], got {}'.format(v.ndim)
-        s, z = _ops.V2S.apply(v, self.linear.weight, self.linear.scale if self.linear.bw else None)
+        s, z = _ops.V2S.apply(v, self.linear.weight, self.linear.scale if self.linear.bw else None, self.training)
         return (s, z) if self.trans_back else s
 
 

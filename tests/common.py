@@ -1,5 +1,6 @@
 """Shared comparison helpers for the parity tests."""
 import os
+import re
 
 import numpy as np
 
@@ -32,9 +33,26 @@ def compare_case(got, ref, rtol, name=""):
         assert g.shape == r.shape, "%s/%s: shape %s vs %s" % (name, k, g.shape, r.shape)
         if r.size == 0:
             continue
-        scale = max(float(np.abs(r).max()), 1e-2 * groups[_kind(k)], 1e-30)
+        # the scale of a linear feeding a train-mode BatchNorm has an exactly-zero true gradient: what any
+        # implementation computes there is rounding noise, so it is compared against the largest gradient of the case
+        floor = 1.0 if re.search(r"linear[12]\.scale$", k) else 1e-2
+        scale = max(float(np.abs(r).max()), floor * groups[_kind(k)], 1e-30)
         err = float(np.abs(g - r).max()) / scale
         if err > worst[0]:
             worst = (err, k)
         assert err <= rtol, "%s/%s: rel err %.3e > %.1e (scale %.3e)" % (name, k, err, rtol, scale)
     return worst
+
+
+def compare_statistical(got, ref, name="", med=1e-4, frac=0.05, big=1e-2):
+    """For multi-layer BINARY stacks in train mode: a 1e-6 difference in one layer's BN output flips a sign()
+    in the next, so element-wise bounds do not hold end to end.  Require instead that the typical element agrees
+    (median relative error < med) and that at most `frac` of the elements moved by more than `big`."""
+    for k, r in ref.items():
+        g = np.asarray(got[k], dtype=np.float64).ravel()
+        r = np.asarray(r, dtype=np.float64).ravel()
+        if r.size == 0:
+            continue
+        e = np.abs(g - r) / max(float(np.abs(r).max()), 1e-30)
+        assert np.median(e) < med, "%s/%s: median rel err %.3e" % (name, k, np.median(e))
+        assert (e > big).mean() <= frac, "%s/%s: %.1f%% of elements off by more than %.0e" % (name, k, 100 * (e > big).mean(), big)
