@@ -63,26 +63,31 @@ int svnet_edge_diffcat_bwd_f32(const float* d_out, const int64_t* idx, int idx_i
 
 /* ------------------------------------------------------------------ generic fp32 GEMM  C[M,N] = epi(sum_k A(i,k) B(k,j))
  * Used for every dense contraction of the path: F.linear of sv_layers.py:31,49 and the autograd
- * products of its backward.  A(i,k) = A[i*a_rs + k*a_cs], B(k,j) = B[k*b_rs + j*b_cs],
+ * products of its backward.  A(i,k) = A[i*a_rs + k*a_cs] * a_scale[k], B(k,j) = B[k*b_rs + j*b_cs],
  * C(i,j) = C[i*ldc + j*c_cs].
- * If a_sign != NULL the A operand is ternary and read from bit-planes instead of fp32:
- *     A(i,k) = nz(i,k) ? (sign(i,k) ? +1 : -1) : 0,  planes are [*, a_ldw] uint64 words,
- *     addressed (i, k) when a_planes_trans == 0 and (k, i) when a_planes_trans == 1.
- * Epilogue, in this order: *alpha, *col_scale[j], +bias[j], *mask(i,j) (mask bit-plane [M, mask_ldw]),
- * then col_sum[j] += sum_i C(i,j) (float atomics, caller zero-fills), then store (or atomic add when
- * split_k > 1; the function zero-fills C itself in that case unless accumulate != 0).                */
+ * Bit-planes are "row-sliced": word [(r >> 6) * W + c] holds bit (r & 63) of column c for rows 64*(r>>6)..+63
+ * (W = number of columns; rows beyond the tensor are 0).  They appear in two places:
+ *   - a_sign/a_nz != NULL: the A operand is ternary, A(i,k) = nz ? (sign ? +1 : -1) : 0, sliced over the
+ *     REDUCTION index k with W = M columns i (this is x_b^T of a binarized layer: weight-gradient products);
+ *   - mask: STE mask of the output, sliced over the output rows i with W = N columns.
+ * b_exact != 0 promises that every B value is exactly representable in bf16 (sign weights: -1, 0, +1), which
+ * lets the tall-and-skinny product run on bf16 MFMA with an exact 3-way split of A.
+ * Epilogue, in this order: *alpha, *col_scale[j], +bias[j], *mask(i,j), then col_sum[j] += sum_i C(i,j) (float
+ * atomics, caller zero-fills), then store (or accumulate when accumulate != 0).                                */
 typedef struct svnet_gemm_desc {
     int64_t M, N, K;
     const float* A; int64_t a_rs, a_cs;
-    const uint64_t* a_sign; const uint64_t* a_nz; int64_t a_ldw; int a_planes_trans;
+    const float* a_scale;
+    const uint64_t* a_sign; const uint64_t* a_nz;
     const float* B; int64_t b_rs, b_cs;
+    int b_exact;
     float* C; int64_t ldc, c_cs;
     float alpha;
     const float* col_scale;
     const float* bias;
-    const uint64_t* mask; int64_t mask_ldw;
+    const uint64_t* mask;
     float* col_sum;
-    int split_k;       /* 0 = choose automatically */
+    int split_k;       /* 0 = choose automatically (vector-ALU kernel only) */
     int accumulate;    /* C += result */
 } svnet_gemm_desc;
 int svnet_gemm_f32(const svnet_gemm_desc* desc, void* stream);
@@ -94,8 +99,9 @@ int svnet_gemm_f32(const svnet_gemm_desc* desc, void* stream);
 int svnet_binweight_prepare_f32(const float* W, const float* scale, int64_t O, int64_t K, uint64_t* w_sign,
                                 uint64_t* w_nz, float* w_b, float* w_eff, void* stream);
 /* y[m,o] = scale[o] * sum_k sgn(x[m,k]+beta[k]) * sgn(W[o,k])  (+bias[o]) by XNOR/popcount on ternary
- * bit-planes.  x row stride ldx.  Optional outputs (NULL to skip), each [M,Kw] uint64:
- *   x_sign, x_nz (sign / non-zero planes of the binarized input), x_ste (|x+beta| <= 1.2).           */
+ * bit-planes.  x row stride ldx.  Optional outputs (NULL to skip), each a row-sliced plane [ceil(M/64), K]
+ * uint64 (layout: see svnet_gemm_desc):  x_sign, x_nz (sign / non-zero planes of the binarized input),
+ * x_ste (|x+beta| <= 1.2).  3 bits per input element replace the saved fp32 input in training.        */
 int svnet_binlinear_fwd_f32(const float* x, int64_t ldx, const float* beta, const uint64_t* w_sign,
                             const uint64_t* w_nz, const float* scale, const float* bias, int64_t M, int64_t K,
                             int64_t O, float* y, uint64_t* x_sign, uint64_t* x_nz, uint64_t* x_ste, void* stream);

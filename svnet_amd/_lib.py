@@ -23,13 +23,15 @@ class GemmDesc(ctypes.Structure):
     _fields_ = [
         ("M", c_i64), ("N", c_i64), ("K", c_i64),
         ("A", c_p), ("a_rs", c_i64), ("a_cs", c_i64),
-        ("a_sign", c_p), ("a_nz", c_p), ("a_ldw", c_i64), ("a_planes_trans", c_int),
+        ("a_scale", c_p),
+        ("a_sign", c_p), ("a_nz", c_p),
         ("B", c_p), ("b_rs", c_i64), ("b_cs", c_i64),
+        ("b_exact", c_int),
         ("C", c_p), ("ldc", c_i64), ("c_cs", c_i64),
         ("alpha", c_f),
         ("col_scale", c_p),
         ("bias", c_p),
-        ("mask", c_p), ("mask_ldw", c_i64),
+        ("mask", c_p),
         ("col_sum", c_p),
         ("split_k", c_int),
         ("accumulate", c_int),

@@ -37,21 +37,21 @@ def _f32c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def gemm(M, N, K, B, b_rs, b_cs, C, ldc, A=None, a_rs=0, a_cs=0, a_planes=None, c_cs=1, alpha=1.0, col_scale=None,
-         bias=None, mask=None, col_sum=None, split_k=0, accumulate=False):
-    """C(i,j) = epilogue(sum_k A(i,k) B(k,j)); see svnet_gemm_desc."""
+def gemm(M, N, K, B, b_rs, b_cs, C, ldc, A=None, a_rs=0, a_cs=0, a_scale=None, a_planes=None, b_exact=False, c_cs=1,
+         alpha=1.0, col_scale=None, bias=None, mask=None, col_sum=None, split_k=0, accumulate=False):
+    """C(i,j) = epilogue(sum_k A(i,k) B(k,j)); see svnet_gemm_desc (bit-planes are row-sliced)."""
     d = GemmDesc()
     d.M, d.N, d.K = M, N, K
     d.A, d.a_rs, d.a_cs = _p(A), a_rs, a_cs
+    d.a_scale = _p(a_scale)
     if a_planes is not None:
-        sg, nz, ldw, trans = a_planes
-        d.a_sign, d.a_nz, d.a_ldw, d.a_planes_trans = _p(sg), _p(nz), ldw, int(trans)
+        d.a_sign, d.a_nz = _p(a_planes[0]), _p(a_planes[1])
     d.B, d.b_rs, d.b_cs = _p(B), b_rs, b_cs
+    d.b_exact = int(b_exact)
     d.C, d.ldc, d.c_cs = _p(C), ldc, c_cs
     d.alpha = alpha
     d.col_scale, d.bias = _p(col_scale), _p(bias)
-    if mask is not None:
-        d.mask, d.mask_ldw = _p(mask[0]), mask[1]
+    d.mask = _p(mask)
     d.col_sum = _p(col_sum)
     d.split_k, d.accumulate = split_k, int(accumulate)
     call("svnet_gemm_f32", ctypes.byref(d), _stream())
@@ -169,25 +169,24 @@ class BwLinear(torch.autograd.Function):
         M, K = x2.shape
         O = W.shape[0]
         w_b = torch.empty((O, K), dtype=torch.float32, device=x.device)
-        w_eff = torch.empty((O, K), dtype=torch.float32, device=x.device)
         sc = _f32c(scale).view(-1)
-        call("svnet_binweight_prepare_f32", _p(W), _p(sc), O, K, None, None, _p(w_b), _p(w_eff), _stream())
+        call("svnet_binweight_prepare_f32", _p(W), _p(sc), O, K, None, None, _p(w_b), None, _stream())
         y = torch.empty((M, O), dtype=torch.float32, device=x.device)
-        gemm(M, O, K, A=x2, a_rs=K, a_cs=1, B=w_b, b_rs=1, b_cs=K, C=y, ldc=O, col_scale=sc)
-        ctx.save_for_backward(x2, W, sc, w_eff)
+        gemm(M, O, K, A=x2, a_rs=K, a_cs=1, B=w_b, b_rs=1, b_cs=K, b_exact=True, C=y, ldc=O, col_scale=sc)
+        ctx.save_for_backward(x2, W, sc, w_b)
         ctx.xshape, ctx.sshape = x.shape, scale.shape
         return y.view(x.shape[:-1] + (O,))
 
     @staticmethod
     def backward(ctx, g):
-        x2, W, sc, w_eff = ctx.saved_tensors
+        x2, W, sc, w_b = ctx.saved_tensors
         M, K = x2.shape
         O = W.shape[0]
         g2 = _f32c(g).reshape(M, O)
         dx = dW = dsc = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((M, K), dtype=torch.float32, device=g.device)
-            gemm(M, K, O, A=g2, a_rs=O, a_cs=1, B=w_eff, b_rs=K, b_cs=1, C=dx, ldc=K)
+            gemm(M, K, O, A=g2, a_rs=O, a_cs=1, a_scale=sc, B=w_b, b_rs=K, b_cs=1, b_exact=True, C=dx, ldc=K)
             dx = dx.view(ctx.xshape)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             GX = torch.empty((O, K), dtype=torch.float32, device=g.device)
@@ -219,20 +218,20 @@ class BinLinear(torch.autograd.Function):
         w_nz = torch.empty((O, KW), dtype=torch.int64, device=dev)
         sc = _f32c(scale).view(-1)
         bt = _f32c(beta).view(-1)
-        w_eff = torch.empty((O, K), dtype=torch.float32, device=dev) if need_grad else None
-        call("svnet_binweight_prepare_f32", _p(W), _p(sc), O, K, _p(w_sign), _p(w_nz), None, _p(w_eff), _stream())
-        planes = [torch.empty((M, KW), dtype=torch.int64, device=dev) for _ in range(3)] if need_grad else [None] * 3
+        w_b = torch.empty((O, K), dtype=torch.float32, device=dev) if need_grad else None
+        call("svnet_binweight_prepare_f32", _p(W), _p(sc), O, K, _p(w_sign), _p(w_nz), _p(w_b), None, _stream())
+        planes = [torch.empty(((M + 63) // 64, K), dtype=torch.int64, device=dev) for _ in range(3)] if need_grad else [None] * 3
         y = torch.empty((M, O), dtype=torch.float32, device=dev)
         call("svnet_binlinear_fwd_f32", _p(x2), K, _p(bt), _p(w_sign), _p(w_nz), _p(sc), _p(bias), M, K, O, _p(y),
                                         _p(planes[0]), _p(planes[1]), _p(planes[2]), _stream())
         if need_grad:
-            ctx.save_for_backward(W, sc, w_eff, *planes)
+            ctx.save_for_backward(W, sc, w_b, *planes)
         ctx.meta = (M, K, O, KW, x.shape, beta.shape, scale.shape, bias is not None)
         return y.view(x.shape[:-1] + (O,))
 
     @staticmethod
     def backward(ctx, g):
-        W, sc, w_eff, x_sign, x_nz, x_ste = ctx.saved_tensors
+        W, sc, w_b, x_sign, x_nz, x_ste = ctx.saved_tensors
         M, K, O, KW, xshape, bshape, sshape, has_bias = ctx.meta
         dev = g.device
         g2 = _f32c(g).reshape(M, O)
@@ -241,7 +240,7 @@ class BinLinear(torch.autograd.Function):
             dbeta = torch.zeros((K,), dtype=torch.float32, device=dev)
             if ctx.training:
                 dx = torch.empty((M, K), dtype=torch.float32, device=dev)
-                gemm(M, K, O, A=g2, a_rs=O, a_cs=1, B=w_eff, b_rs=K, b_cs=1, C=dx, ldc=K, mask=(x_ste, KW), col_sum=dbeta)
+                gemm(M, K, O, A=g2, a_rs=O, a_cs=1, a_scale=sc, B=w_b, b_rs=K, b_cs=1, b_exact=True, C=dx, ldc=K, mask=x_ste, col_sum=dbeta)
             else:   # eval: bare sign() has zero gradient (sv_layers.py:38-39)
                 dx = torch.zeros((M, K), dtype=torch.float32, device=dev)
             dx = dx.view(xshape)
@@ -249,7 +248,7 @@ class BinLinear(torch.autograd.Function):
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[3]:
             # GX[o,k] = sum_m g[m,o] x_b[m,k], computed as (x_b^T g)[k,o] with the ternary operand on the A side
             GX = torch.empty((O, K), dtype=torch.float32, device=dev)
-            gemm(K, O, M, a_planes=(x_sign, x_nz, KW, True), B=g2, b_rs=O, b_cs=1, C=GX, ldc=1, c_cs=K)
+            gemm(K, O, M, a_planes=(x_sign, x_nz), B=g2, b_rs=O, b_cs=1, C=GX, ldc=1, c_cs=K)
             dW = torch.zeros((O, K), dtype=torch.float32, device=dev)
             dsc = torch.zeros((O,), dtype=torch.float32, device=dev)
             call("svnet_binweight_grad_f32", _p(GX), _p(W), _p(sc), O, K, _p(dW) if ctx.training else None, _p(dsc), _stream())

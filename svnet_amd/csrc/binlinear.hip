@@ -110,13 +110,23 @@ __global__ __launch_bounds__(256) void binlinear_fwd_kernel(const float* __restr
             }
         }
         __syncthreads();
-        // ---- saved planes (training): the tile's rows are contiguous in the [M,KW] planes
+        // ---- saved planes (training), written ROW-SLICED: word [tile*K + k] = bit r of column k for the tile's
+        // 64 rows (a 64x64 bit transpose per word by 64 ballots; rows beyond M contribute 0).  This is the layout
+        // the backward MFMA kernels consume with one coalesced u64 per lane (gemm_mfma.hip).
         if (x_sign) {
-            const int n = rows * KW;
-            for (int e = tid; e < n; e += 256) {
-                x_sign[row0 * KW + e] = ls[e];
-                x_nz[row0 * KW + e] = lz[e];
-                x_ste[row0 * KW + e] = lt[e];
+            for (int item = wave; item < 3 * KW; item += 4) {
+                const int pl = item / KW, w = item - pl * KW;
+                const uint64_t* src = (pl == 0) ? ls : ((pl == 1) ? lz : lt);
+                uint64_t* dst = (pl == 0) ? x_sign : ((pl == 1) ? x_nz : x_ste);
+                const uint64_t mine_row = (lane < rows) ? src[lane * KW + w] : 0ull;
+                uint64_t col_word = 0ull;
+#pragma unroll 8
+                for (int b = 0; b < 64; ++b) {
+                    const uint64_t t = __ballot((mine_row >> b) & 1ull);
+                    if (lane == b) col_word = t;
+                }
+                const int k = w * 64 + lane;
+                if (k < K) dst[tile * K + k] = col_word;
             }
         }
         // ---- phase 2: popcount dot products

@@ -1,13 +1,18 @@
-// Generic fp32 GEMM with strided / ternary-bit-plane operands and a fused epilogue.
+// svnet_gemm_f32: dispatcher + the generic fp32 vector-ALU GEMM.
 //
-// Serves every dense contraction on the path: F.linear of sv_layers.py:31,49 (fp layers, the
-// sign-weight vector linear `linear2`, the gate, the classifier) and the autograd products of their
-// backward (dX = G.W, GX = G^T.X with X fp32 or ternary bit-planes).
-// Shapes are tall-and-skinny (M up to 2.6 M rows, N,K <= 2144), i.e. HBM-bound: 64x64x16 LDS tiles,
-// 4x4 register micro-tiles on the vector ALUs, split-K with float atomics when the output is tiny and
-// the reduction long (weight gradients).  (A CDNA4 f32-MFMA variant is the planned upgrade for the
-// two genuinely dense shapes, conv5 505->512 / 83->170.)
+// Serves every dense contraction on the path: F.linear of sv_layers.py:31,49 (fp layers, the sign-weight
+// vector linear `linear2`, the gate, the classifier) and the autograd products of their backward.
+// Dispatch (all shapes are tall-and-skinny, i.e. HBM-bound):
+//   * B exact in bf16 (sign weights) and A row-major        -> mfma_rows_kernel   (gemm_mfma.hip)
+//   * reduction over the rows (weight gradients), K >= 1024 -> mfma_tn_kernel     (fp32 or ternary-plane operand)
+//   * everything else (small fp layers, K <= 12 ...)         -> gemm_kernel below: 64x64x16 LDS tiles, 4x4 register
+//     micro-tiles on the vector ALUs, strided operands, split-K with float atomics.
 #include "common.h"
+
+int svnet_mfma_rows(const svnet_gemm_desc& d, hipStream_t st);
+int svnet_mfma_tn(const float* A, int64_t lda, const float* B, int64_t ldb, const uint64_t* b_sign, const uint64_t* b_nz,
+                  int64_t M, int64_t P, int64_t Q, float* C, int64_t c_ps, int64_t c_qs, float alpha, int accumulate,
+                  hipStream_t st);
 
 namespace {
 
@@ -18,14 +23,6 @@ struct GemmArgs {
     int64_t k_chunk;
     int atomic_out;
 };
-
-__device__ __forceinline__ float tern_elem(const uint64_t* __restrict__ sg, const uint64_t* __restrict__ nz, int64_t ldw,
-                                           int64_t r, int64_t c) {
-    const uint64_t w_nz = nz[r * ldw + (c >> 6)];
-    const uint64_t w_sg = sg[r * ldw + (c >> 6)];
-    const uint64_t bit = 1ull << (c & 63);
-    return (w_nz & bit) ? ((w_sg & bit) ? 1.f : -1.f) : 0.f;
-}
 
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs ga) {
     const svnet_gemm_desc& d = ga.d;
@@ -44,8 +41,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs ga) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
 
-    const bool a_tern = d.a_sign != nullptr;
-    const bool a_k_fast = a_tern ? (d.a_planes_trans == 0) : (d.a_cs == 1 || d.a_rs != 1);
+    const bool a_k_fast = (d.a_cs == 1 || d.a_rs != 1);
     const bool b_k_fast = (d.b_rs == 1 && d.b_cs != 1);
 
     for (int64_t kb = k_begin; kb < k_end; kb += BK) {
@@ -57,9 +53,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs ga) {
             const int64_t gi = i0 + ii, gk = kb + kk;
             float v = 0.f;
             if (gi < d.M && gk < k_end) {
-                if (a_tern) v = d.a_planes_trans ? tern_elem(d.a_sign, d.a_nz, d.a_ldw, gk, gi)
-                                                 : tern_elem(d.a_sign, d.a_nz, d.a_ldw, gi, gk);
-                else v = d.A[gi * d.a_rs + gk * d.a_cs];
+                v = d.A[gi * d.a_rs + gk * d.a_cs];
+                if (d.a_scale) v *= d.a_scale[gk];
             }
             As[kk][ii] = v;
         }
@@ -101,8 +96,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs ga) {
                 if (d.col_scale) v *= d.col_scale[gj];
                 if (d.bias && blockIdx.z == 0) v += d.bias[gj];
                 if (d.mask) {
-                    const uint64_t w = d.mask[gi * d.mask_ldw + (gj >> 6)];
-                    if (!((w >> (gj & 63)) & 1ull)) v = 0.f;
+                    const uint64_t w = d.mask[(gi >> 6) * d.N + gj];
+                    if (!((w >> (gi & 63)) & 1ull)) v = 0.f;
                 }
                 colpart[c] += v;
                 float* dst = d.C + gi * d.ldc + gj * d.c_cs;
@@ -145,6 +140,21 @@ extern "C" int svnet_gemm_f32(const svnet_gemm_desc* desc, void* stream) {
     SVNET_REQUIRE(d.c_cs != 0 && d.ldc != 0, SVNET_E_ARG, "svnet_gemm_f32: zero C stride");
     if (d.M == 0 || d.N == 0) return SVNET_OK;
     hipStream_t st = (hipStream_t)stream;
+    const bool plain_epi = !d.col_scale && !d.bias && !d.mask && !d.col_sum && !d.a_scale;
+
+    // ---- ternary A (row-sliced planes over the reduction index): C(i,j) = sum_k tern(i,k) * B[k*b_rs + j]
+    if (d.a_sign) {
+        SVNET_REQUIRE(d.b_cs == 1 && plain_epi, SVNET_E_UNSUPPORTED, "svnet_gemm_f32: ternary A needs row-major B and a plain epilogue");
+        return svnet_mfma_tn(d.B, d.b_rs, nullptr, 0, d.a_sign, d.a_nz, d.K, /*P=*/d.N, /*Q=*/d.M, d.C, /*c_ps=*/d.c_cs,
+                             /*c_qs=*/d.ldc, d.alpha, d.accumulate, st);
+    }
+    // ---- reduction over rows with both operands fp32 rows: A(i,k) = A[k*a_cs + i], B(k,j) = B[k*b_rs + j]
+    if (d.a_rs == 1 && d.b_cs == 1 && d.K >= 1024 && plain_epi && d.M <= 1024 && d.N <= 1024) {
+        return svnet_mfma_tn(d.A, d.a_cs, d.B, d.b_rs, nullptr, nullptr, d.K, /*P=*/d.M, /*Q=*/d.N, d.C, d.ldc, d.c_cs, d.alpha,
+                             d.accumulate, st);
+    }
+    // ---- rows x exact-bf16 weights
+    if (d.b_exact && d.a_cs == 1 && d.c_cs == 1 && d.M >= 256 && d.K >= 8) return svnet_mfma_rows(d, st);
 
     GemmArgs ga;
     ga.d = d;
