@@ -187,3 +187,105 @@ def test_cpu_tensors_are_refused():
     from svnet_amd.models.utils.sv_util import knn
     with pytest.raises(RuntimeError):
         knn(torch.zeros(1, 3, 8), 2)
+
+
+# ----------------------------------------------------------------------------- MFMA GEMM paths (large-M shapes)
+
+def _planes_row_sliced(x_b, dev):
+    """ternary [M,K] (cpu) -> row-sliced sign / nz planes [ceil(M/64), K] int64 on dev"""
+    M, K = x_b.shape
+    Mp = (M + 63) // 64 * 64
+    pad = torch.zeros(Mp, K)
+    pad[:M] = x_b
+    bits = (1 << torch.arange(64, dtype=torch.int64)).view(1, 64, 1)
+    sg = ((pad > 0).view(-1, 64, K).long() * bits).sum(1)
+    nz = ((pad != 0).view(-1, 64, K).long() * bits).sum(1)
+    return sg.to(dev), nz.to(dev)
+
+
+@pytest.mark.parametrize("M,K,N", [(1000, 42, 21), (5000, 128, 254), (777, 20, 10), (4096, 505, 512), (300, 83, 170)])
+def test_gemm_rows_mfma_exact_weights(M, K, N, hip_device):
+    """rows x sign-weights on bf16 MFMA with the exact 3-way split, incl. a_scale, col_scale, STE mask, column sums."""
+    from svnet_amd import _ops
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=g)
+    Wb = torch.sign(torch.randn(N, K, generator=g))
+    Wb[0, 0] = 0.0
+    asc = torch.rand(K, generator=g) + 0.5
+    csc = torch.rand(N, generator=g) + 0.5
+    keep = (torch.rand(M, N, generator=g) > 0.3).float()
+    msg, _ = _planes_row_sliced(keep, hip_device)
+    ref = ((A * asc).double() @ Wb.t().double() * csc.double()) * keep.double()
+    C = torch.empty(M, N, device=hip_device)
+    cs = torch.zeros(N, device=hip_device)
+    _ops.gemm(M, N, K, A=A.to(hip_device), a_rs=K, a_cs=1, a_scale=asc.to(hip_device), B=Wb.to(hip_device), b_rs=1, b_cs=K,
+              b_exact=True, C=C, ldc=N, col_scale=csc.to(hip_device), mask=msg, col_sum=cs)
+    assert H.max_rel_err(C.cpu().numpy(), ref.numpy()) < 2e-6
+    assert H.max_rel_err(cs.cpu().numpy(), ref.sum(0).numpy()) < 1e-5
+    # NN orientation (dx = g . w_b): B(k,j) = Wb2[k*N + j]
+    Wb2 = torch.sign(torch.randn(K, N, generator=g))
+    C2 = torch.empty(M, N, device=hip_device)
+    _ops.gemm(M, N, K, A=A.to(hip_device), a_rs=K, a_cs=1, B=Wb2.to(hip_device), b_rs=N, b_cs=1, b_exact=True, C=C2, ldc=N)
+    assert H.max_rel_err(C2.cpu().numpy(), (A.double() @ Wb2.double()).numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("R,P,Q", [(3000, 70, 200), (70000, 128, 254), (2049, 10, 20), (5000, 170, 83), (1500, 512, 505)])
+def test_gemm_tn_mfma(R, P, Q, hip_device):
+    """weight-gradient products: reduction over R rows, fp32 x fp32 (6-term split) and fp32 x ternary planes."""
+    from svnet_amd import _ops
+    g = torch.Generator().manual_seed(R + P)
+    G = torch.randn(R, P, generator=g)
+    X = torch.randn(R, Q, generator=g)
+    out = torch.empty(P, Q, device=hip_device)
+    _ops.gemm(P, Q, R, A=G.to(hip_device), a_rs=1, a_cs=P, B=X.to(hip_device), b_rs=Q, b_cs=1, C=out, ldc=Q)
+    assert H.max_rel_err(out.cpu().numpy(), (G.double().t() @ X.double()).numpy()) < 5e-6
+    Xb = torch.sign(torch.randn(R, Q, generator=g)) * (torch.rand(R, Q, generator=g) > 0.1)
+    sg, nz = _planes_row_sliced(Xb, hip_device)
+    gx = torch.empty(P, Q, device=hip_device)                    # GX[p,q] = sum_r G[r,p] Xb[r,q], written through C strides
+    _ops.gemm(Q, P, R, a_planes=(sg, nz), B=G.to(hip_device), b_rs=P, b_cs=1, C=gx, ldc=1, c_cs=Q)
+    assert H.max_rel_err(gx.cpu().numpy(), (G.double().t() @ Xb.double()).numpy()) < 5e-6
+
+
+@pytest.mark.parametrize("M,K,O", [(1500, 254, 128), (700, 124, 32), (330, 505, 512)])
+def test_binlinear_large_train_matches_oracle(M, K, O, hip_device):
+    """Linear(bw,ba) at conv-sized rows: XNOR forward, row-sliced planes, MFMA backward; against the oracle."""
+    from svnet_amd.models.sv_layers import Linear
+    params = H.module_params("Linear", (K, O, False, True, True), "big%d" % M)
+    x = C.t("big_lin/%d" % M, (M, K), 1.0)
+    x.view(-1)[::11] = 0.0
+    params["beta"][:, ::5] = 0.0
+    r = C.t("big_lin_r/%d" % M, (M, O))
+    m = Linear(K, O, False, bw=True, ba=True)
+    m.load_state_dict(params)
+    m = m.to(hip_device).train()
+    xd = x.to(hip_device).requires_grad_(True)
+    y = m(xd)
+    (y * r.to(hip_device)).sum().backward()
+    P = {"m." + k: v.clone().requires_grad_(True) for k, v in params.items()}
+    xo = x.clone().requires_grad_(True)
+    yo = sv_ref.linear(xo, P, "m", bw=True, ba=True, ctx=sv_ref.Ctx(train=True))
+    (yo * r).sum().backward()
+    got = {"out0": y.detach().cpu().numpy(), "dx0": xd.grad.cpu().numpy(), "d:weight": m.weight.grad.cpu().numpy(),
+           "d:beta": m.beta.grad.cpu().numpy(), "d:scale": m.scale.grad.cpu().numpy()}
+    ref = {"out0": yo.detach().numpy(), "dx0": xo.grad.numpy(), "d:weight": P["m.weight"].grad.numpy(),
+           "d:beta": P["m.beta"].grad.numpy(), "d:scale": P["m.scale"].grad.numpy()}
+    compare_case(got, ref, RTOL, "binlinear large")
+
+
+def test_bwlinear_large_train_matches_oracle(hip_device):
+    from svnet_amd.models.sv_layers import Linear
+    K, O, rows = 42, 42, (40, 33, 3)
+    params = H.module_params("Linear", (K, O, False, True, False), "bigbw")
+    x = C.t("big_bw/x", rows + (K,), 1.0)
+    r = C.t("big_bw/r", rows + (O,))
+    m = Linear(K, O, False, bw=True)
+    m.load_state_dict(params)
+    m = m.to(hip_device).train()
+    xd = x.to(hip_device).requires_grad_(True)
+    (m(xd) * r.to(hip_device)).sum().backward()
+    P = {"m." + k: v.clone().requires_grad_(True) for k, v in params.items()}
+    xo = x.clone().requires_grad_(True)
+    (sv_ref.linear(xo, P, "m", bw=True, ctx=sv_ref.Ctx(train=True)) * r).sum().backward()
+    got = {"dx0": xd.grad.cpu().numpy(), "d:weight": m.weight.grad.cpu().numpy(), "d:scale": m.scale.grad.cpu().numpy()}
+    ref = {"dx0": xo.grad.numpy(), "d:weight": P["m.weight"].grad.numpy(), "d:scale": P["m.scale"].grad.numpy()}
+    compare_case(got, ref, RTOL, "bwlinear large")
