@@ -110,6 +110,43 @@ int svnet_binlinear_fwd_f32(const float* x, int64_t ldx, const float* beta, cons
 int svnet_binweight_grad_f32(const float* GX, const float* W, const float* scale, int64_t O, int64_t K,
                              float* dW, float* dscale, void* stream);
 
+/* ------------------------------------------------------------------ fused edge block (tier 2)
+ * One pass over the edges of a BINARIZED edge layer, never materialising an edge tensor:
+ *   get_graph_feature_sv (sv_util.py:90-116) -> SVBlock (sv_layers.py:172-196) -> svpool (sv_util.py:118-132).
+ * Inputs are point tables: s [P,Cs], v [P,3,Cv], idx [P,k] (cloud-local), and two small per-point products that
+ * the linear maps on v_e = [v_j - v_i, v_i] collapse to:
+ *   zz [P,3,6]    = [Zp | Zq],  Zp = v . (scale_z*sign(Wz[:, :Cv]))^T,  Zq = v . (scale_z*sign(Wz[:, Cv:]))^T   (v2s frame)
+ *   ut [P,3,2Ov]  = [U  | T ],  U  = v . (scale2*sign(W2[:, :Cv]))^T,   T  = v . (scale2*sign(W2[:, Cv:]))^T    (linear2)
+ * linear1's sign planes / beta are permuted once into the kernel's bit order (5 words: s_j-s_i | s_i | s_v[:,0] |
+ * s_v[:,1] | s_v[:,2]) by svnet_edgeblock_prepare_f32.  Limits: Cs <= 64, 2*Cv <= 64, Os <= 128, Ov <= 64, k <= 255.
+ * Per-point outputs: n_max/n_min [P,Os] (extreme integer popcount sums over the k neighbours) with their slots,
+ * mv/mvn [P,3,Ov] (mean_k v', mean_k v'/|v'|); batch statistics as exact integer sums stat_n [2*Os] (sum n, sum n^2)
+ * and fp64 sums stat_v [2*Ov]; gate_sum [B,2Cs] = sum over the cloud's edges of [s_j-s_i, s_i] (caller zero-fills
+ * stat_*, gate_sum; stat_* may both be NULL in eval mode).                                                      */
+typedef struct svnet_edgeblock_desc {
+    int64_t B, N, k;
+    int Cs, Cv, Os, Ov;
+    const float* s; const float* v; const int64_t* idx;
+    const float* zz; const float* ut;
+    const uint64_t* w_sign; const uint64_t* w_nz; const float* beta_perm;
+    int32_t* n_max; int32_t* n_min; uint8_t* slot_max; uint8_t* slot_min;
+    float* mv; float* mvn;
+    int64_t* stat_n; double* stat_v; float* gate_sum;
+} svnet_edgeblock_desc;
+int svnet_edgeblock_prepare_f32(const float* W, const float* beta, int64_t Os, int64_t Cs, int64_t Cv, uint64_t* w_sign,
+                                uint64_t* w_nz, float* beta_perm /*[5*64]*/, void* stream);
+int svnet_edgeblock_fwd_f32(const svnet_edgeblock_desc* desc, void* stream);
+/* coef [4*Os + 4*Ov] = [A1 | B1 | mean_y | invstd_y | Av | Bv | mean_n' | invstd_n']: BatchNorm folded into
+ * y = A1*n + B1 and q = Av + Bv/n'; training != 0 uses the batch sums (E = B*N*k edges) and updates running_*.   */
+int svnet_edgeblock_coeffs_f32(const int64_t* stat_n, const double* stat_v, int64_t E, int64_t Os, int64_t Ov,
+                               const float* scale1, const float* gamma1, const float* beta1, float* running_mean1,
+                               float* running_var1, const float* gamma2, const float* beta2, float* running_mean2,
+                               float* running_var2, int training, float eps, float momentum, float* coef, void* stream);
+/* s_out[P,Os] = leaky_relu(A1*(A1>=0 ? n_max : n_min) + B1);  v_out[P,3,Ov] = gate[b]*(Av*mv + Bv*mvn).          */
+int svnet_edgeblock_apply_f32(const int32_t* n_max, const int32_t* n_min, const float* mv, const float* mvn,
+                              const float* coef, const float* gate, int64_t P, int64_t N, int64_t Os, int64_t Ov,
+                              float slope, float* s_out, float* v_out, void* stream);
+
 /* ------------------------------------------------------------------ Vector2Scalar (sv_layers.py:104-129)
  * v: [M,3,C]; w_eff: [J,C] effective weights (scale*sign(W) or W); z[m,i,j] = sum_c v[m,i,c] w_eff[j,c];
  * s[m, d*J+j] = sum_i v[m,i,d] z[m,i,j].  z_out optional ([M,3,J]).  J <= 4, C <= 192.              */

@@ -38,6 +38,20 @@ class GemmDesc(ctypes.Structure):
     ]
 
 
+class EdgeBlockDesc(ctypes.Structure):
+    """struct svnet_edgeblock_desc (include/svnet_hip.h)."""
+    _fields_ = [
+        ("B", c_i64), ("N", c_i64), ("k", c_i64),
+        ("Cs", c_int), ("Cv", c_int), ("Os", c_int), ("Ov", c_int),
+        ("s", c_p), ("v", c_p), ("idx", c_p),
+        ("zz", c_p), ("ut", c_p),
+        ("w_sign", c_p), ("w_nz", c_p), ("beta_perm", c_p),
+        ("n_max", c_p), ("n_min", c_p), ("slot_max", c_p), ("slot_min", c_p),
+        ("mv", c_p), ("mvn", c_p),
+        ("stat_n", c_p), ("stat_v", c_p), ("gate_sum", c_p),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/svnet_hip.h declares
 SIGNATURES = {
     "svnet_version": (c_int, []),
@@ -51,6 +65,10 @@ SIGNATURES = {
     "svnet_binweight_prepare_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),
     "svnet_binlinear_fwd_f32": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),
     "svnet_binweight_grad_f32": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p]),
+    "svnet_edgeblock_prepare_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p]),
+    "svnet_edgeblock_fwd_f32": (c_int, [ctypes.POINTER(EdgeBlockDesc), c_p]),
+    "svnet_edgeblock_coeffs_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_f, c_f, c_p, c_p]),
+    "svnet_edgeblock_apply_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p]),
     "svnet_v2s_fwd_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "svnet_v2s_bwd_f32": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "svnet_colstats_f64": (c_int, [c_p, c_i64, c_i64, c_int, c_p, c_p]),

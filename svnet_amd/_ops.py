@@ -478,3 +478,92 @@ class SmoothCE(torch.autograd.Function):
     def backward(ctx, g):
         (dlog,) = ctx.saved_tensors
         return dlog * g, None, None
+
+
+# ----------------------------------------------------------------------------- fused edge block (tier 2)
+
+def _act_raw(x, kind):
+    y = torch.empty_like(x)
+    call("svnet_act_fwd_f32", _p(x), x.numel(), kind, _p(y), _stream())
+    return y
+
+
+class EdgeBlock(torch.autograd.Function):
+    """get_graph_feature_sv -> binarized SVBlock -> svpool(max, mean) in one pass over the edges
+    (csrc/edgeblock.hip).  Inputs are the POINT tables; no edge tensor is materialised in either direction."""
+
+    @staticmethod
+    def forward(ctx, s, v, idx, k, training, Wz, scz, W1, beta1, scale1, g1, b1, rm1, rv1, W2, sc2, g2, b2, rm2, rv2, Wg0, Wg2):
+        _hip(s, v, idx)
+        from ._lib import EdgeBlockDesc
+        s = _f32c(s)
+        v = _f32c(v)
+        B, N, Cs = s.shape
+        Cv = v.shape[-1]
+        Os, Ov = W1.shape[0], W2.shape[0]
+        P, E = B * N, B * N * k
+        dev = s.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        idx = idx.contiguous()
+
+        # per-point pieces of the two linear maps on v_e = [v_j - v_i, v_i]
+        wz_b = torch.empty((3, 2 * Cv), **f32)
+        w2_b = torch.empty((Ov, 2 * Cv), **f32)
+        call("svnet_binweight_prepare_f32", _p(_f32c(Wz)), None, 3, 2 * Cv, None, None, _p(wz_b), None, _stream())
+        call("svnet_binweight_prepare_f32", _p(_f32c(W2)), None, Ov, 2 * Cv, None, None, _p(w2_b), None, _stream())
+        wzz = torch.cat((wz_b[:, :Cv], wz_b[:, Cv:]), dim=0).contiguous()            # [6,Cv]
+        w2c = torch.cat((w2_b[:, :Cv], w2_b[:, Cv:]), dim=0).contiguous()            # [2Ov,Cv]
+        scz2 = torch.cat((scz.reshape(-1), scz.reshape(-1)))
+        sc22 = torch.cat((sc2.reshape(-1), sc2.reshape(-1)))
+        zz = torch.empty((P * 3, 6), **f32)
+        ut = torch.empty((P * 3, 2 * Ov), **f32)
+        gemm(3 * P, 6, Cv, A=v, a_rs=Cv, a_cs=1, B=wzz, b_rs=1, b_cs=Cv, b_exact=True, C=zz, ldc=6, col_scale=scz2)
+        gemm(3 * P, 2 * Ov, Cv, A=v, a_rs=Cv, a_cs=1, B=w2c, b_rs=1, b_cs=Cv, b_exact=True, C=ut, ldc=2 * Ov, col_scale=sc22)
+
+        w_sign = torch.empty((Os, 5), dtype=torch.int64, device=dev)
+        w_nz = torch.empty((Os, 5), dtype=torch.int64, device=dev)
+        beta_perm = torch.empty((5 * 64,), **f32)
+        call("svnet_edgeblock_prepare_f32", _p(_f32c(W1)), _p(_f32c(beta1)), Os, Cs, Cv, _p(w_sign), _p(w_nz), _p(beta_perm), _stream())
+
+        n_max = torch.empty((P, Os), dtype=torch.int32, device=dev)
+        n_min = torch.empty((P, Os), dtype=torch.int32, device=dev)
+        slot_max = torch.empty((P, Os), dtype=torch.uint8, device=dev)
+        slot_min = torch.empty((P, Os), dtype=torch.uint8, device=dev)
+        mv = torch.empty((P, 3, Ov), **f32)
+        mvn = torch.empty((P, 3, Ov), **f32)
+        stat_n = torch.zeros((2 * Os,), dtype=torch.int64, device=dev) if training else None
+        stat_v = torch.zeros((2 * Ov,), dtype=torch.float64, device=dev) if training else None
+        gate_sum = torch.zeros((B, 2 * Cs), **f32)
+        d = EdgeBlockDesc()
+        d.B, d.N, d.k = B, N, k
+        d.Cs, d.Cv, d.Os, d.Ov = Cs, Cv, Os, Ov
+        d.s, d.v, d.idx, d.zz, d.ut = _p(s), _p(v), _p(idx), _p(zz), _p(ut)
+        d.w_sign, d.w_nz, d.beta_perm = _p(w_sign), _p(w_nz), _p(beta_perm)
+        d.n_max, d.n_min, d.slot_max, d.slot_min = _p(n_max), _p(n_min), _p(slot_max), _p(slot_min)
+        d.mv, d.mvn, d.stat_n, d.stat_v, d.gate_sum = _p(mv), _p(mvn), _p(stat_n), _p(stat_v), _p(gate_sum)
+        call("svnet_edgeblock_fwd_f32", ctypes.byref(d), _stream())
+
+        # gate MLP on the mean edge scalar (sv_layers.py:156-161,179-183): tiny [B,.] products
+        gin = gate_sum * (1.0 / float(N * k))
+        H = Wg0.shape[0]
+        hpre = torch.empty((B, H), **f32)
+        gemm(B, H, 2 * Cs, A=gin, a_rs=2 * Cs, a_cs=1, B=_f32c(Wg0), b_rs=1, b_cs=2 * Cs, C=hpre, ldc=H)
+        h = _act_raw(hpre, 1)
+        gpre = torch.empty((B, Ov), **f32)
+        gemm(B, Ov, H, A=h, a_rs=H, a_cs=1, B=_f32c(Wg2), b_rs=1, b_cs=H, C=gpre, ldc=Ov)
+        gate = _act_raw(gpre, 2)
+
+        coef = torch.empty((4 * Os + 4 * Ov,), **f32)
+        call("svnet_edgeblock_coeffs_f32", _p(stat_n), _p(stat_v), E, Os, Ov, _p(scale1.reshape(-1)), _p(g1), _p(b1), _p(rm1), _p(rv1),
+             _p(g2), _p(b2), _p(rm2), _p(rv2), int(training), BN_EPS, BN_MOMENTUM, _p(coef), _stream())
+        s_out = torch.empty((B, N, Os), **f32)
+        v_out = torch.empty((B, N, 3, Ov), **f32)
+        call("svnet_edgeblock_apply_f32", _p(n_max), _p(n_min), _p(mv), _p(mvn), _p(coef), _p(gate), P, N, Os, Ov, 0.2, _p(s_out),
+             _p(v_out), _stream())
+        ctx.mark_non_differentiable()
+        ctx.saved = None
+        return s_out, v_out
+
+    @staticmethod
+    def backward(ctx, gs, gv):
+        raise NotImplementedError("EdgeBlock.backward")

@@ -1,0 +1,356 @@
+// Fused edge block (tier 2): k-NN gather -> binarized SVBlock -> neighbour pooling in ONE pass over the edges,
+// without ever writing an edge tensor to HBM.
+//
+// Replaces, for a binarized edge layer (conv2/3/4 of sv_dgcnn_cls.py:55-65), the chain
+//   get_graph_feature_sv (sv_util.py:90-116) -> SVBlock.forward (sv_layers.py:172-196) -> svpool (sv_util.py:118-132).
+// Algebra that makes the single pass possible (re-derived in DESIGN.md §4.2):
+//   * linear maps applied to v_e = [v_j - v_i, v_i] collapse to per-POINT products:
+//       z(e)  = Zp[j] - Zp[i] + Zq[i]            (Vector2Scalar frame, 3x3)
+//       v'(e) = U[j]  - U[i]  + T[i]             (linear2, 3 x Ov)
+//     so the edge loop only gathers rows of small point tables (L2 / Infinity-Cache resident);
+//   * pre-BN scalar outputs are scale*n with integer n (ternary popcount), BatchNorm+LeakyReLU is monotone per
+//     channel, so max_k commutes with it: only max_k n, min_k n (and their slots) and the exact integer sums
+//     sum n, sum n^2 are needed;
+//   * VectorBN is affine in (v', v'/|v'|): mean_k out = gate * (Av * mean_k v' + Bv * mean_k v'/n').
+// One wave per point; lanes are channels.  The five ternary words of an edge row (s_j-s_i | s_i | s_v[:,0..2]) are
+// produced by wave ballots in a lane-friendly bit order; linear1's sign planes are permuted to that order once.
+#include <limits.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr float VEPS = 1e-6f;
+constexpr int NW = 5;  // ternary words per edge row in fused bit order
+
+__device__ __forceinline__ int tdot(uint64_t xs, uint64_t xz, uint64_t ws, uint64_t wz) {
+    const uint64_t m = xz & wz;
+    return __popcll(m) - 2 * __popcll(m & (xs ^ ws));
+}
+
+// feature index of (word, bit) in the reference's K1 ordering [s_j-s_i (Cs) | s_i (Cs) | s_v (2Cv x 3)], or -1
+__device__ __forceinline__ int fused_feature(int w, int b, int Cs, int Cv) {
+    if (w == 0) return b < Cs ? b : -1;
+    if (w == 1) return b < Cs ? Cs + b : -1;
+    return b < 2 * Cv ? 2 * Cs + b * 3 + (w - 2) : -1;
+}
+
+__global__ void edgeblock_prepare_kernel(const float* __restrict__ W, const float* __restrict__ beta, int Os, int Cs, int Cv,
+                                         uint64_t* __restrict__ w_sign, uint64_t* __restrict__ w_nz, float* __restrict__ beta_perm) {
+    const int K1 = 2 * Cs + 6 * Cv;
+    const int total = Os * NW;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total + NW * 64; e += gridDim.x * blockDim.x) {
+        if (e < total) {
+            const int o = e / NW, w = e - o * NW;
+            uint64_t sg = 0, nz = 0;
+            for (int b = 0; b < 64; ++b) {
+                const int f = fused_feature(w, b, Cs, Cv);
+                if (f >= 0) {
+                    const float v = W[(int64_t)o * K1 + f];
+                    if (v > 0.f) sg |= 1ull << b;
+                    if (v != 0.f) nz |= 1ull << b;
+                }
+            }
+            w_sign[e] = sg;
+            w_nz[e] = nz;
+        } else {
+            const int q = e - total, w = q / 64, b = q - w * 64;
+            const int f = fused_feature(w, b, Cs, Cv);
+            beta_perm[q] = f >= 0 ? beta[f] : 0.f;
+        }
+    }
+}
+
+struct FwdArgs {
+    svnet_edgeblock_desc d;
+    int waves_per_cloud, points_per_wave;
+};
+
+// OP = scalar outputs per lane (Os <= 64*OP)
+template <int OP>
+__global__ __launch_bounds__(256) void edgeblock_fwd_kernel(FwdArgs fa) {
+    const svnet_edgeblock_desc& d = fa.d;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t b = wave_g / fa.waves_per_cloud;
+    if (b >= d.B) return;  // wave-uniform, no barriers in this kernel
+    const int wi = (int)(wave_g - b * fa.waves_per_cloud);
+    const int p_begin = wi * fa.points_per_wave;
+    const int p_end = min((int)d.N, p_begin + fa.points_per_wave);
+    const int Cs = d.Cs, Cv = d.Cv, Os = d.Os, Ov = d.Ov, k = (int)d.k;
+
+    // my output channels' weight words
+    uint64_t wsg[OP][NW], wnz[OP][NW];
+#pragma unroll
+    for (int op = 0; op < OP; ++op) {
+        const int o = lane + 64 * op;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            wsg[op][w] = (o < Os) ? d.w_sign[o * NW + w] : 0ull;
+            wnz[op][w] = (o < Os) ? d.w_nz[o * NW + w] : 0ull;
+        }
+    }
+    const float bd = d.beta_perm[lane], bc = d.beta_perm[64 + lane];
+    float bv[3];
+#pragma unroll
+    for (int jz = 0; jz < 3; ++jz) bv[jz] = d.beta_perm[128 + 64 * jz + lane];
+
+    const bool s_lane = lane < Cs;
+    const bool v2_lane = lane < 2 * Cv;
+    const bool diff_lane = lane < Cv;
+    const int cm = diff_lane ? lane : lane - Cv;
+    const bool o_lane = lane < Ov;
+
+    long long sn[OP], sn2[OP];
+#pragma unroll
+    for (int op = 0; op < OP; ++op) sn[op] = sn2[op] = 0;
+    double sv1 = 0.0, sv2 = 0.0;
+    float gs_diff = 0.f, gs_cen = 0.f;
+
+    for (int p = p_begin; p < p_end; ++p) {
+        const int64_t gp = b * d.N + p;
+        const float s_i = s_lane ? d.s[gp * Cs + lane] : 0.f;
+        gs_cen += s_i;
+        const float tc = s_i + bc;
+        const uint64_t csg = __ballot(s_lane && tc > 0.f), cnz = __ballot(s_lane && tc != 0.f);
+        int base[OP];
+#pragma unroll
+        for (int op = 0; op < OP; ++op) base[op] = tdot(csg, cnz, wsg[op][1], wnz[op][1]);
+
+        float vi[3], zi[3][3], ub[3];
+#pragma unroll
+        for (int dd = 0; dd < 3; ++dd) {
+            vi[dd] = v2_lane ? d.v[(gp * 3 + dd) * Cv + cm] : 0.f;
+            const float* zrow = d.zz + (gp * 3 + dd) * 6;
+#pragma unroll
+            for (int jz = 0; jz < 3; ++jz) zi[dd][jz] = zrow[3 + jz] - zrow[jz];  // Zq_i - Zp_i
+            ub[dd] = o_lane ? d.ut[(gp * 3 + dd) * 2 * Ov + Ov + lane] - d.ut[(gp * 3 + dd) * 2 * Ov + lane] : 0.f;  // T_i - U_i
+        }
+        int nmax[OP], nmin[OP], smax[OP], smin[OP];
+#pragma unroll
+        for (int op = 0; op < OP; ++op) { nmax[op] = INT_MIN; nmin[op] = INT_MAX; smax[op] = 0; smin[op] = 0; }
+        float av[3] = {0.f, 0.f, 0.f}, avn[3] = {0.f, 0.f, 0.f};
+
+        for (int t = 0; t < k; ++t) {
+            const int64_t gj = b * d.N + d.idx[gp * k + t];
+            const float sd = (s_lane ? d.s[gj * Cs + lane] : 0.f) - s_i;
+            gs_diff += sd;
+            const float td = sd + bd;
+            const uint64_t dsg = __ballot(s_lane && td > 0.f), dnz = __ballot(s_lane && td != 0.f);
+            float ve[3], z[3][3];
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd) {
+                const float vj = diff_lane ? d.v[(gj * 3 + dd) * Cv + lane] : 0.f;
+                ve[dd] = diff_lane ? (vj - vi[dd]) : vi[dd];
+                const float* zrow = d.zz + (gj * 3 + dd) * 6;
+#pragma unroll
+                for (int jz = 0; jz < 3; ++jz) z[dd][jz] = zrow[jz] + zi[dd][jz];
+            }
+            uint64_t vsg[3], vnz[3];
+#pragma unroll
+            for (int jz = 0; jz < 3; ++jz) {
+                const float tv = ve[0] * z[0][jz] + ve[1] * z[1][jz] + ve[2] * z[2][jz] + bv[jz];
+                vsg[jz] = __ballot(v2_lane && tv > 0.f);
+                vnz[jz] = __ballot(v2_lane && tv != 0.f);
+            }
+#pragma unroll
+            for (int op = 0; op < OP; ++op) {
+                int n = base[op] + tdot(dsg, dnz, wsg[op][0], wnz[op][0]);
+#pragma unroll
+                for (int jz = 0; jz < 3; ++jz) n += tdot(vsg[jz], vnz[jz], wsg[op][2 + jz], wnz[op][2 + jz]);
+                if (n > nmax[op]) { nmax[op] = n; smax[op] = t; }
+                if (n < nmin[op]) { nmin[op] = n; smin[op] = t; }
+                sn[op] += n;
+                sn2[op] += n * n;
+            }
+            float vp[3];
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd) vp[dd] = (o_lane ? d.ut[(gj * 3 + dd) * 2 * Ov + lane] : 0.f) + ub[dd];
+            const float nn = sqrtf(vp[0] * vp[0] + vp[1] * vp[1] + vp[2] * vp[2]) + VEPS;
+            const float inv = 1.f / nn;
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd) { av[dd] += vp[dd]; avn[dd] += vp[dd] * inv; }
+            sv1 += (double)nn;
+            sv2 += (double)nn * (double)nn;
+        }
+        const float invk = 1.f / (float)k;
+#pragma unroll
+        for (int op = 0; op < OP; ++op) {
+            const int o = lane + 64 * op;
+            if (o < Os) {
+                d.n_max[gp * Os + o] = nmax[op];
+                d.n_min[gp * Os + o] = nmin[op];
+                d.slot_max[gp * Os + o] = (uint8_t)smax[op];
+                d.slot_min[gp * Os + o] = (uint8_t)smin[op];
+            }
+        }
+        if (o_lane) {
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd) {
+                d.mv[(gp * 3 + dd) * Ov + lane] = av[dd] * invk;
+                d.mvn[(gp * 3 + dd) * Ov + lane] = avn[dd] * invk;
+            }
+        }
+    }
+    if (p_begin < p_end) {
+        if (d.stat_n) {
+#pragma unroll
+            for (int op = 0; op < OP; ++op) {
+                const int o = lane + 64 * op;
+                if (o < Os) {
+                    atomicAdd(reinterpret_cast<unsigned long long*>(d.stat_n) + o, (unsigned long long)sn[op]);
+                    atomicAdd(reinterpret_cast<unsigned long long*>(d.stat_n) + Os + o, (unsigned long long)sn2[op]);
+                }
+            }
+            if (o_lane) {
+                atomicAdd(&d.stat_v[lane], sv1);
+                atomicAdd(&d.stat_v[Ov + lane], sv2);
+            }
+        }
+        if (s_lane) {
+            atomicAdd(&d.gate_sum[b * 2 * Cs + lane], gs_diff);
+            atomicAdd(&d.gate_sum[b * 2 * Cs + Cs + lane], gs_cen * (float)k);
+        }
+    }
+}
+
+// Per-channel affine forms from the batch (or running) statistics.
+//   scalar: y = A1*n + B1 with A1 = gamma*scale*invstd_y,  B1 = beta - gamma*mean_y*invstd_y   (y_pre = scale*n)
+//   vector: q(n') = Av + Bv/n' with Av = gamma'*invstd', Bv = beta' - gamma'*mean'*invstd'
+// coef layout: [A1 (Os) | B1 (Os) | mean_y (Os) | invstd_y (Os) | Av (Ov) | Bv (Ov) | mean' (Ov) | invstd' (Ov)]
+__global__ void edgeblock_coeffs_kernel(const long long* __restrict__ stat_n, const double* __restrict__ stat_v, int64_t E, int Os,
+                                        int Ov, const float* __restrict__ scale1, const float* __restrict__ g1,
+                                        const float* __restrict__ b1, float* __restrict__ rm1, float* __restrict__ rv1,
+                                        const float* __restrict__ g2, const float* __restrict__ b2, float* __restrict__ rm2,
+                                        float* __restrict__ rv2, int training, float eps, float momentum,
+                                        float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    float* A1 = coef; float* B1 = coef + Os; float* MY = coef + 2 * Os; float* IY = coef + 3 * Os;
+    float* Av = coef + 4 * Os; float* Bv = Av + Ov; float* MV = Av + 2 * Ov; float* IV = Av + 3 * Ov;
+    if (c < Os) {
+        float mean, invstd;
+        if (training) {
+            const double sc = (double)scale1[c];
+            const double mn = (double)stat_n[c] / (double)E;
+            double var_n = (double)stat_n[Os + c] / (double)E - mn * mn;
+            if (var_n < 0.0) var_n = 0.0;
+            const double m = sc * mn, var = sc * sc * var_n;
+            mean = (float)m;
+            invstd = (float)(1.0 / sqrt(var + (double)eps));
+            if (rm1) rm1[c] = (1.f - momentum) * rm1[c] + momentum * mean;
+            if (rv1) rv1[c] = (1.f - momentum) * rv1[c] + momentum * (float)(E > 1 ? var * ((double)E / (double)(E - 1)) : var);
+        } else {
+            mean = rm1[c];
+            invstd = 1.f / sqrtf(rv1[c] + eps);
+        }
+        A1[c] = g1[c] * scale1[c] * invstd;
+        B1[c] = b1[c] - g1[c] * mean * invstd;
+        MY[c] = mean;
+        IY[c] = invstd;
+    }
+    if (c < Ov) {
+        float mean, invstd;
+        if (training) {
+            const double m = stat_v[c] / (double)E;
+            double var = stat_v[Ov + c] / (double)E - m * m;
+            if (var < 0.0) var = 0.0;
+            mean = (float)m;
+            invstd = (float)(1.0 / sqrt(var + (double)eps));
+            if (rm2) rm2[c] = (1.f - momentum) * rm2[c] + momentum * mean;
+            if (rv2) rv2[c] = (1.f - momentum) * rv2[c] + momentum * (float)(E > 1 ? var * ((double)E / (double)(E - 1)) : var);
+        } else {
+            mean = rm2[c];
+            invstd = 1.f / sqrtf(rv2[c] + eps);
+        }
+        Av[c] = g2[c] * invstd;
+        Bv[c] = b2[c] - g2[c] * mean * invstd;
+        MV[c] = mean;
+        IV[c] = invstd;
+    }
+}
+
+// Pooled outputs: s_out = lrelu(A1 * (A1 >= 0 ? n_max : n_min) + B1); v_out = gate * (Av*mv + Bv*mvn).
+__global__ __launch_bounds__(256) void edgeblock_apply_kernel(const int32_t* __restrict__ n_max, const int32_t* __restrict__ n_min,
+                                                              const float* __restrict__ mv, const float* __restrict__ mvn,
+                                                              const float* __restrict__ coef, const float* __restrict__ gate,
+                                                              int64_t P, int64_t N, int Os, int Ov, float slope,
+                                                              float* __restrict__ s_out, float* __restrict__ v_out) {
+    const float* A1 = coef; const float* B1 = coef + Os; const float* Av = coef + 4 * Os; const float* Bv = Av + Ov;
+    const int64_t ts = P * Os, tv = P * 3 * Ov;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < ts + tv; e += (int64_t)gridDim.x * blockDim.x) {
+        if (e < ts) {
+            const int o = (int)(e % Os);
+            const float a = A1[o];
+            const float y = a * (float)(a >= 0.f ? n_max[e] : n_min[e]) + B1[o];
+            s_out[e] = y > 0.f ? y : y * slope;
+        } else {
+            const int64_t q = e - ts;
+            const int c = (int)(q % Ov);
+            const int64_t p = q / (3 * Ov);
+            v_out[q] = gate[(p / N) * Ov + c] * (Av[c] * mv[q] + Bv[c] * mvn[q]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int svnet_edgeblock_prepare_f32(const float* W, const float* beta, int64_t Os, int64_t Cs, int64_t Cv, uint64_t* w_sign,
+                                           uint64_t* w_nz, float* beta_perm, void* stream) {
+    SVNET_REQUIRE(W && beta && w_sign && w_nz && beta_perm, SVNET_E_ARG, "svnet_edgeblock_prepare_f32: null pointer");
+    SVNET_REQUIRE(Cs > 0 && Cs <= 64 && Cv > 0 && 2 * Cv <= 64 && Os > 0, SVNET_E_UNSUPPORTED, "svnet_edgeblock_prepare_f32: needs Cs <= 64, 2*Cv <= 64");
+    hipLaunchKernelGGL(edgeblock_prepare_kernel, dim3((unsigned)svnet_cdiv(Os * NW + NW * 64, 256)), dim3(256), 0, (hipStream_t)stream, W,
+                       beta, (int)Os, (int)Cs, (int)Cv, w_sign, w_nz, beta_perm);
+    SVNET_CHECK_LAUNCH("edgeblock_prepare_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_edgeblock_fwd_f32(const svnet_edgeblock_desc* desc, void* stream) {
+    SVNET_REQUIRE(desc, SVNET_E_ARG, "svnet_edgeblock_fwd_f32: null descriptor");
+    const svnet_edgeblock_desc& d = *desc;
+    SVNET_REQUIRE(d.s && d.v && d.idx && d.zz && d.ut && d.w_sign && d.w_nz && d.beta_perm && d.n_max && d.n_min && d.slot_max &&
+                      d.slot_min && d.mv && d.mvn && d.gate_sum, SVNET_E_ARG, "svnet_edgeblock_fwd_f32: null pointer");
+    SVNET_REQUIRE((d.stat_n == nullptr) == (d.stat_v == nullptr), SVNET_E_ARG, "svnet_edgeblock_fwd_f32: pass both stat buffers or none");
+    SVNET_REQUIRE(d.B >= 0 && d.N > 0 && d.k > 0 && d.k <= 255, SVNET_E_ARG, "svnet_edgeblock_fwd_f32: bad sizes");
+    SVNET_REQUIRE(d.Cs > 0 && d.Cs <= 64 && d.Cv > 0 && 2 * d.Cv <= 64 && d.Os > 0 && d.Os <= 128 && d.Ov > 0 && d.Ov <= 64,
+                  SVNET_E_UNSUPPORTED, "svnet_edgeblock_fwd_f32: channel counts outside Cs<=64, 2Cv<=64, Os<=128, Ov<=64");
+    if (d.B == 0) return SVNET_OK;
+    FwdArgs fa;
+    fa.d = d;
+    int wpc = (int)svnet_cdiv(4096, d.B);                 // ~4096 waves in flight (16 per CU)
+    if (wpc > d.N) wpc = (int)d.N;
+    if (wpc < 1) wpc = 1;
+    fa.points_per_wave = (int)svnet_cdiv(d.N, wpc);
+    fa.waves_per_cloud = (int)svnet_cdiv(d.N, fa.points_per_wave);
+    const int64_t waves = d.B * fa.waves_per_cloud;
+    const unsigned grid = (unsigned)svnet_cdiv(waves, 4);
+    if (d.Os <= 64) hipLaunchKernelGGL((edgeblock_fwd_kernel<1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, fa);
+    else hipLaunchKernelGGL((edgeblock_fwd_kernel<2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, fa);
+    SVNET_CHECK_LAUNCH("edgeblock_fwd_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_edgeblock_coeffs_f32(const int64_t* stat_n, const double* stat_v, int64_t E, int64_t Os, int64_t Ov,
+                                          const float* scale1, const float* gamma1, const float* beta1, float* running_mean1,
+                                          float* running_var1, const float* gamma2, const float* beta2, float* running_mean2,
+                                          float* running_var2, int training, float eps, float momentum, float* coef, void* stream) {
+    SVNET_REQUIRE(scale1 && gamma1 && beta1 && gamma2 && beta2 && coef && E > 0 && Os > 0 && Ov > 0, SVNET_E_ARG, "svnet_edgeblock_coeffs_f32: bad arguments");
+    SVNET_REQUIRE(training ? (stat_n && stat_v) : (running_mean1 && running_var1 && running_mean2 && running_var2), SVNET_E_ARG,
+                  "svnet_edgeblock_coeffs_f32: missing statistics");
+    const int64_t n = Os > Ov ? Os : Ov;
+    hipLaunchKernelGGL(edgeblock_coeffs_kernel, dim3((unsigned)svnet_cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream,
+                       reinterpret_cast<const long long*>(stat_n), stat_v, E, (int)Os, (int)Ov, scale1, gamma1, beta1, running_mean1,
+                       running_var1, gamma2, beta2, running_mean2, running_var2, training, eps, momentum, coef);
+    SVNET_CHECK_LAUNCH("edgeblock_coeffs_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_edgeblock_apply_f32(const int32_t* n_max, const int32_t* n_min, const float* mv, const float* mvn,
+                                         const float* coef, const float* gate, int64_t P, int64_t N, int64_t Os, int64_t Ov,
+                                         float slope, float* s_out, float* v_out, void* stream) {
+    SVNET_REQUIRE(n_max && n_min && mv && mvn && coef && gate && s_out && v_out && P >= 0 && N > 0, SVNET_E_ARG, "svnet_edgeblock_apply_f32: bad arguments");
+    if (P == 0) return SVNET_OK;
+    hipLaunchKernelGGL(edgeblock_apply_kernel, dim3(svnet_grid(P * (Os + 3 * Ov), 256)), dim3(256), 0, (hipStream_t)stream, n_max, n_min,
+                       mv, mvn, coef, gate, P, N, (int)Os, (int)Ov, slope, s_out, v_out);
+    SVNET_CHECK_LAUNCH("edgeblock_apply_kernel");
+    return SVNET_OK;
+}

@@ -19,7 +19,7 @@ import torch.nn.init as init
 import torch.nn.functional as F
 
 from .. import _ops
-from .utils.sv_util import svpool
+from .utils.sv_util import svpool, EdgeFeatures
 
 EPS = 1e-6
 
@@ -137,6 +137,44 @@ class VectorReLU(nn.Module):
         return torch.where(length > threshold, rows, torch.zeros_like(rows)).view(shape_x)
 
 
+class PendingEdgeBlock:
+    """SVBlock applied to lazy EdgeFeatures: a stand-in for the tuple (s, v) of per-edge outputs.  svpool(max over
+    the k neighbours) consumes it with the fused kernel; any other use materialises the edges and runs the
+    layer-by-layer path, so behaviour is unchanged."""
+
+    def __init__(self, block, edges):
+        self.block, self.edges, self._out = block, edges, None
+
+    def pooled(self, dim, keepdim, spool):
+        if dim != 2 or spool != 'max' or self._out is not None:
+            return None
+        b, e = self.block, self.edges
+        bn1, bn2 = b.bn1, b.bn2.bn
+        training = b.training
+        if training:
+            bn1.num_batches_tracked.add_(1)
+            bn2.num_batches_tracked.add_(1)
+        s, v = _ops.EdgeBlock.apply(
+            e.s, e.v, e.idx, e.k, training, b.v2s.linear.weight, b.v2s.linear.scale, b.linear1.weight, b.linear1.beta,
+            b.linear1.scale, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, b.linear2.weight, b.linear2.scale,
+            bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, b.gate[0].weight, b.gate[2].weight)
+        return (s.unsqueeze(2), v.unsqueeze(2)) if keepdim else (s, v)
+
+    def materialize(self):
+        if self._out is None:
+            self._out = self.block._forward_rows(self.edges.materialize())
+        return self._out
+
+    def __iter__(self):
+        return iter(self.materialize())
+
+    def __getitem__(self, i):
+        return self.materialize()[i]
+
+    def __len__(self):
+        return 2
+
+
 class SVBlock(nn.Module):
     """One scalar/vector layer: gate from the mean scalar, invariant scalars from the vectors, (binarized)
     scalar linear + BN + LeakyReLU, (sign-weight) vector linear + VectorBN, vectors scaled by the gate."""
@@ -165,11 +203,24 @@ class SVBlock(nn.Module):
         h = _ops.Act.apply(_ops.FpLinear.apply(pooled, self.gate[0].weight, None), 1)   # ReLU
         return _ops.Act.apply(_ops.FpLinear.apply(h, self.gate[2].weight, None), 2)     # Sigmoid -> [B, Cv_out]
 
+    def _can_fuse(self, edges):
+        lin1, lin2 = self.linear1, self.linear2
+        if not (lin1.bw and lin1.ba and lin2.bw and self.v2s.linear.bw) or edges.idx_is_global:
+            return False
+        Cs, Cv = edges.s.shape[-1], edges.v.shape[-1]
+        return (Cs <= 64 and 2 * Cv <= 64 and lin1.out_features <= 128 and lin2.out_features <= 64 and edges.k <= 255
+                and lin1.in_features == 2 * Cs + 6 * Cv and self.bn1.track_running_stats and self.bn2.bn.track_running_stats)
+
     def forward(self, x):
         '''
         shape of s: B, N_points, [k,] s_dim
         shape of v: B, N_points, [k,] 3, v_dim
         '''
+        if isinstance(x, EdgeFeatures) and self._can_fuse(x):
+            return PendingEdgeBlock(self, x)
+        return self._forward_rows(x)
+
+    def _forward_rows(self, x):
         s, v = x
         v_scale = self._gate(s)
 

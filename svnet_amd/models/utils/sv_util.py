@@ -16,6 +16,34 @@ import torch.nn.init as init
 import torch.nn.functional as F
 
 from ... import _ops
+from ... import config
+
+
+class EdgeFeatures:
+    """What get_graph_feature_sv returns when edge fusion is on: behaves like the tuple (s_e, v_e) — `s, v = x`,
+    `x[0]`, `len(x)` materialise the edge tensors on demand — but lets SVBlock + svpool consume the POINT tables and
+    the neighbour ids directly, so that a binarized edge layer never writes an edge tensor to HBM."""
+
+    def __init__(self, s, v, idx, k, idx_is_global):
+        self.s, self.v, self.idx, self.k, self.idx_is_global = s, v, idx, k, idx_is_global
+        self._edges = None
+
+    def materialize(self):
+        if self._edges is None:
+            B, N, Cs = self.s.shape
+            s_e = _ops.EdgeDiffcat.apply(self.s.reshape(B, N, 1, Cs), self.idx, self.idx_is_global, self.k).view(B, N, self.k, 2 * Cs)
+            v_e = _ops.EdgeDiffcat.apply(self.v, self.idx, self.idx_is_global, self.k)
+            self._edges = (s_e, v_e)
+        return self._edges
+
+    def __iter__(self):
+        return iter(self.materialize())
+
+    def __getitem__(self, i):
+        return self.materialize()[i]
+
+    def __len__(self):
+        return 2
 
 __all__ = ["knn", "get_graph_feature", "get_graph_feature_cross", "get_graph_feature_sv", "svpool", "svcat",
            "torch", "nn", "F", "np", "math", "os", "sys", "copy", "init"]
@@ -62,13 +90,16 @@ def get_graph_feature_sv(x, k=20, idx=None):
         idx = _ops.knn(feat.transpose(-1, -2), k)
     else:
         idx = idx.reshape(B, N, k)
-    s_e = _ops.EdgeDiffcat.apply(s.reshape(B, N, 1, Cs), idx, is_global, k).view(B, N, k, 2 * Cs)
-    v_e = _ops.EdgeDiffcat.apply(v, idx, is_global, k)
-    return (s_e, v_e)
+    edges = EdgeFeatures(s, v, idx, k, is_global)
+    return edges if config.FUSE_EDGE_BLOCKS else edges.materialize()
 
 
 def svpool(x, dim=2, keepdim=False, spool='max'):
     """s: max (or mean) over `dim`; v: mean over `dim`.  Max ties send the gradient to the first index."""
+    if hasattr(x, "pooled"):                       # a pending fused edge block (sv_layers.PendingEdgeBlock)
+        fused = x.pooled(dim, keepdim, spool)
+        if fused is not None:
+            return fused
     s, v = x
     if spool == 'max':
         s = _ops.Pool.apply(s, dim, 0)

@@ -1,0 +1,71 @@
+"""GPU tests (-m gpu) of the fused edge block (csrc/edgeblock.hip) against the layer-by-layer HIP path (tier 1,
+itself pinned to the oracle by test_hip_parity.py) and against the oracle, on identical inputs."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sv_ref
+from tests.common import compare_case
+from tests.golden import cases as C
+from tests.golden import harness as H
+
+pytestmark = pytest.mark.gpu
+
+# (Cs, Cv) point tables -> (Os, Ov); B, N, k
+SHAPES = [((32, 10), (32, 10), 2, 96, 6), ((32, 10), (64, 21), 2, 80, 7), ((64, 21), (128, 42), 2, 130, 20),
+          ((64, 24), (128, 40), 1, 70, 40)]
+
+
+def _make(shape, dev, train, tag):
+    from svnet_amd.models.sv_layers import SVBlock
+    (Cs, Cv), (Os, Ov), B, N, k = shape
+    in_dims, out_dims = (2 * Cs, 2 * Cv), (Os, Ov)
+    params = H.module_params("SVBlock", (in_dims, out_dims, True), tag)
+    params["linear1.beta"][:, ::4] = 0.0
+    with contextlib.redirect_stdout(io.StringIO()):
+        blk = SVBlock(in_dims, out_dims, binary=True)
+    blk.load_state_dict(params)
+    blk = blk.to(dev).train(train)
+    s, v = C.sv_pair(tag + "/pt", (B, N), Cs, Cv, 1.0)
+    s = torch.round(s * 4) / 4                         # discrete scalars like a binary net's: exact zeros / ties
+    return blk, params, s, v, (in_dims, out_dims, B, N, k)
+
+
+def _run(blk, s, v, k, dev, fuse, grad=False):
+    from svnet_amd import config
+    from svnet_amd.models.utils.sv_util import get_graph_feature_sv, svpool
+    old = config.FUSE_EDGE_BLOCKS
+    config.FUSE_EDGE_BLOCKS = fuse
+    try:
+        sd = s.to(dev).requires_grad_(grad)
+        vd = v.to(dev).requires_grad_(grad)
+        out = svpool(blk(get_graph_feature_sv((sd, vd), k=k)))
+    finally:
+        config.FUSE_EDGE_BLOCKS = old
+    return sd, vd, out
+
+
+@pytest.mark.parametrize("train", [False, True], ids=["eval", "train"])
+@pytest.mark.parametrize("shape", SHAPES, ids=[str(i) for i in range(len(SHAPES))])
+def test_fused_forward_matches_layerwise_and_oracle(shape, train, hip_device):
+    blk, params, s, v, (in_dims, out_dims, B, N, k) = _make(shape, hip_device, train, "fused_fwd")
+    with torch.no_grad():
+        _, _, (fs, fv) = _run(blk, s, v, k, hip_device, True)
+        bufs_f = {n: b.detach().cpu().numpy().copy() for n, b in blk.named_buffers() if b.is_floating_point()}
+        blk.load_state_dict(params)
+        _, _, (ls, lv) = _run(blk, s, v, k, hip_device, False)
+        bufs_l = {n: b.detach().cpu().numpy() for n, b in blk.named_buffers() if b.is_floating_point()}
+    got = {"out0": fs.cpu().numpy(), "out1": fv.cpu().numpy()}
+    ref = {"out0": ls.cpu().numpy(), "out1": lv.cpu().numpy()}
+    compare_case(got, ref, 1e-4, "fused vs layerwise")
+    if train:
+        compare_case({"buf:" + n: x for n, x in bufs_f.items()}, {"buf:" + n: x for n, x in bufs_l.items()}, 1e-4, "running stats")
+    # oracle on the same inputs
+    P = {"m." + n: t.clone() for n, t in params.items()}
+    ctx = sv_ref.Ctx(train=train)
+    with torch.no_grad():
+        os_, ov = sv_ref.svpool(sv_ref.svblock(sv_ref.graph_feature_sv((s, v), k=k), P, "m", True, ctx))
+    compare_case(got, {"out0": os_.numpy(), "out1": ov.numpy()}, 1e-4, "fused vs oracle")
