@@ -147,6 +147,44 @@ int svnet_edgeblock_apply_f32(const int32_t* n_max, const int32_t* n_min, const 
                               const float* coef, const float* gate, int64_t P, int64_t N, int64_t Os, int64_t Ov,
                               float slope, float* s_out, float* v_out, void* stream);
 
+/* Backward of the fused edge block: a point-level prelude reduces the batch-statistic terms of both BatchNorms,
+ * then ONE pass over the edges recomputes the forward quantities from the point tables and produces all gradients
+ * (csrc/edgeblock_bwd.hip).  Outputs of svnet_edgeblock_bwd_f32 (caller zero-fills every *_acc, dvc, dzc, dbeta_perm):
+ *   dn_out [E,Os]            dL/d(scale*n) per edge          -> GX = dn_out^T . x_b via svnet_gemm_f32 (ternary A)
+ *   x_sign32/x_nz32          row-sliced planes of x_b in fused column order, [ceil(E/64), 320] uint64 viewed as uint32
+ *   ds_acc [P,Cs], dv_acc [P,3,Cv]   gradients of the point tables (binarized + gate + v2s paths)
+ *   du_acc/dvc [P,3,Ov]      neighbour / centre sums of dL/dv'   (dU = du_acc - dvc, dT = dvc)
+ *   dzp_acc/dzc [P,3,3]      neighbour / centre sums of dL/dz    (dZp = dzp_acc - dzc, dZq = dzc)
+ *   dbeta_perm [320]         dL/dbeta in fused column order                                                      */
+typedef struct svnet_edgeblock_bwd_desc {
+    int64_t B, N, k;
+    int Cs, Cv, Os, Ov;
+    const float* s; const float* v; const int64_t* idx; const float* zz; const float* ut;
+    const uint64_t* w_sign; const uint64_t* w_nz; const float* beta_perm;
+    const uint16_t* w1bt;        /* svnet_edgeblock_wbt_bf16: sign(W1) as bf16 [320][Os] */
+    const float* scale1;
+    const uint8_t* slot_max; const uint8_t* slot_min;
+    const float* coef;           /* from svnet_edgeblock_coeffs_f32 */
+    const float* gate;           /* [B,Ov] */
+    const float* gy;             /* [P,Os] from the prelude */
+    const float* bcoef;          /* [3*Os + 2*Ov] from svnet_edgeblock_bwd_coeffs_f32 */
+    const float* gv;             /* upstream gradient of v_out [P,3,Ov] */
+    const float* gconst;         /* [B,2Cs]: dL/d(gate input) / (N*k) */
+    float* dn_out; uint32_t* x_sign32; uint32_t* x_nz32;
+    float* ds_acc; float* dv_acc; float* du_acc; float* dvc; float* dzp_acc; float* dzc; float* dbeta_perm;
+} svnet_edgeblock_bwd_desc;
+int svnet_edgeblock_wbt_bf16(const uint64_t* w_sign, const uint64_t* w_nz, int64_t Os, uint16_t* wbt, void* stream);
+/* gy = Gs*lrelu'(y) at the pooled edge; red [2*Os], redv [2*Ov], dgate [B,Ov] accumulate (caller zero-fills).      */
+int svnet_edgeblock_bwd_prelude_f32(const float* gs, const float* gv, const int32_t* n_max, const int32_t* n_min,
+                                    const float* mv, const float* mvn, const float* coef, const float* scale1,
+                                    const float* gate, int64_t P, int64_t N, int64_t Os, int64_t Ov, float slope,
+                                    float* gy, float* red, float* redv, float* dgate, void* stream);
+/* bcoef = [m1 | m2 | cs | c0 | c1]; BatchNorm parameter gradients are written to dgamma*, dbeta*.                   */
+int svnet_edgeblock_bwd_coeffs_f32(const float* red, const float* redv, const float* coef, const float* gamma1,
+                                   const float* gamma2, int64_t E, int64_t Os, int64_t Ov, int training, float* bcoef,
+                                   float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, void* stream);
+int svnet_edgeblock_bwd_f32(const svnet_edgeblock_bwd_desc* desc, void* stream);
+
 /* ------------------------------------------------------------------ Vector2Scalar (sv_layers.py:104-129)
  * v: [M,3,C]; w_eff: [J,C] effective weights (scale*sign(W) or W); z[m,i,j] = sum_c v[m,i,c] w_eff[j,c];
  * s[m, d*J+j] = sum_i v[m,i,d] z[m,i,j].  z_out optional ([M,3,J]).  J <= 4, C <= 192.              */

@@ -52,6 +52,22 @@ class EdgeBlockDesc(ctypes.Structure):
     ]
 
 
+class EdgeBlockBwdDesc(ctypes.Structure):
+    """struct svnet_edgeblock_bwd_desc (include/svnet_hip.h)."""
+    _fields_ = [
+        ("B", c_i64), ("N", c_i64), ("k", c_i64),
+        ("Cs", c_int), ("Cv", c_int), ("Os", c_int), ("Ov", c_int),
+        ("s", c_p), ("v", c_p), ("idx", c_p), ("zz", c_p), ("ut", c_p),
+        ("w_sign", c_p), ("w_nz", c_p), ("beta_perm", c_p),
+        ("w1bt", c_p),
+        ("scale1", c_p),
+        ("slot_max", c_p), ("slot_min", c_p),
+        ("coef", c_p), ("gate", c_p), ("gy", c_p), ("bcoef", c_p), ("gv", c_p), ("gconst", c_p),
+        ("dn_out", c_p), ("x_sign32", c_p), ("x_nz32", c_p),
+        ("ds_acc", c_p), ("dv_acc", c_p), ("du_acc", c_p), ("dvc", c_p), ("dzp_acc", c_p), ("dzc", c_p), ("dbeta_perm", c_p),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/svnet_hip.h declares
 SIGNATURES = {
     "svnet_version": (c_int, []),
@@ -69,6 +85,10 @@ SIGNATURES = {
     "svnet_edgeblock_fwd_f32": (c_int, [ctypes.POINTER(EdgeBlockDesc), c_p]),
     "svnet_edgeblock_coeffs_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_f, c_f, c_p, c_p]),
     "svnet_edgeblock_apply_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p]),
+    "svnet_edgeblock_wbt_bf16": (c_int, [c_p, c_p, c_i64, c_p, c_p]),
+    "svnet_edgeblock_bwd_prelude_f32": (c_int, [c_p] * 9 + [c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p, c_p, c_p]),
+    "svnet_edgeblock_bwd_coeffs_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "svnet_edgeblock_bwd_f32": (c_int, [ctypes.POINTER(EdgeBlockBwdDesc), c_p]),
     "svnet_v2s_fwd_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "svnet_v2s_bwd_f32": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "svnet_colstats_f64": (c_int, [c_p, c_i64, c_i64, c_int, c_p, c_p]),

@@ -560,10 +560,121 @@ class EdgeBlock(torch.autograd.Function):
         v_out = torch.empty((B, N, 3, Ov), **f32)
         call("svnet_edgeblock_apply_f32", _p(n_max), _p(n_min), _p(mv), _p(mvn), _p(coef), _p(gate), P, N, Os, Ov, 0.2, _p(s_out),
              _p(v_out), _stream())
-        ctx.mark_non_differentiable()
-        ctx.saved = None
+        ctx.save_for_backward(s, v, idx, zz, ut, w_sign, w_nz, beta_perm, n_max, n_min, slot_max, slot_min, mv, mvn, coef, gate, h,
+                              gin, wzz, w2c, scz2, sc22, W1, scale1, W2, sc2, Wz, scz, g1, g2, Wg0, Wg2)
+        ctx.meta = (B, N, k, Cs, Cv, Os, Ov, bool(training))
         return s_out, v_out
 
     @staticmethod
     def backward(ctx, gs, gv):
-        raise NotImplementedError("EdgeBlock.backward")
+        from ._lib import EdgeBlockBwdDesc
+        (s, v, idx, zz, ut, w_sign, w_nz, beta_perm, n_max, n_min, slot_max, slot_min, mv, mvn, coef, gate, h, gin, wzz, w2c,
+         scz2, sc22, W1, scale1, W2, sc2, Wz, scz, g1, g2, Wg0, Wg2) = ctx.saved_tensors
+        B, N, k, Cs, Cv, Os, Ov, training = ctx.meta
+        P, E = B * N, B * N * k
+        dev = s.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        gs = _f32c(gs).reshape(P, Os)
+        gv = _f32c(gv).reshape(P, 3, Ov)
+        sc1 = scale1.reshape(-1)
+
+        # ---- point-level prelude: BatchNorm reductions, gate gradient
+        gy = torch.empty((P, Os), **f32)
+        red = torch.zeros((2 * Os,), **f32)
+        redv = torch.zeros((2 * Ov,), **f32)
+        dgate = torch.zeros((B, Ov), **f32)
+        call("svnet_edgeblock_bwd_prelude_f32", _p(gs), _p(gv), _p(n_max), _p(n_min), _p(mv), _p(mvn), _p(coef), _p(sc1), _p(gate),
+             P, N, Os, Ov, 0.2, _p(gy), _p(red), _p(redv), _p(dgate), _stream())
+        bcoef = torch.empty((3 * Os + 2 * Ov,), **f32)
+        dg1, db1 = torch.empty((Os,), **f32), torch.empty((Os,), **f32)
+        dg2, db2 = torch.empty((Ov,), **f32), torch.empty((Ov,), **f32)
+        call("svnet_edgeblock_bwd_coeffs_f32", _p(red), _p(redv), _p(coef), _p(g1), _p(g2), E, Os, Ov, int(training), _p(bcoef), _p(dg1),
+             _p(db1), _p(dg2), _p(db2), _stream())
+
+        # ---- gate MLP backward (tiny [B,.] products)
+        H = Wg0.shape[0]
+        dgpre = torch.empty_like(dgate)
+        call("svnet_act_bwd_f32", _p(dgate), _p(gate), dgate.numel(), 2, _p(dgpre), _stream())
+        dWg2 = torch.empty((Ov, H), **f32)
+        gemm(Ov, H, B, A=dgpre, a_rs=1, a_cs=Ov, B=h, b_rs=H, b_cs=1, C=dWg2, ldc=H)
+        dh = torch.empty((B, H), **f32)
+        gemm(B, H, Ov, A=dgpre, a_rs=Ov, a_cs=1, B=_f32c(Wg2), b_rs=H, b_cs=1, C=dh, ldc=H)
+        dhpre = torch.empty_like(dh)
+        call("svnet_act_bwd_f32", _p(dh), _p(h), dh.numel(), 1, _p(dhpre), _stream())
+        dWg0 = torch.empty((H, 2 * Cs), **f32)
+        gemm(H, 2 * Cs, B, A=dhpre, a_rs=1, a_cs=H, B=gin, b_rs=2 * Cs, b_cs=1, C=dWg0, ldc=2 * Cs)
+        gconst = torch.empty((B, 2 * Cs), **f32)
+        gemm(B, 2 * Cs, H, A=dhpre, a_rs=H, a_cs=1, B=_f32c(Wg0), b_rs=2 * Cs, b_cs=1, C=gconst, ldc=2 * Cs, alpha=1.0 / float(N * k))
+
+        # ---- the edge pass
+        wbt = torch.empty((320 * Os,), dtype=torch.int16, device=dev)
+        call("svnet_edgeblock_wbt_bf16", _p(w_sign), _p(w_nz), Os, _p(wbt), _stream())
+        dn_out = torch.empty((E, Os), **f32)
+        x_sign = torch.empty(((E + 63) // 64, 320), dtype=torch.int64, device=dev)
+        x_nz = torch.empty(((E + 63) // 64, 320), dtype=torch.int64, device=dev)
+        ds_acc = torch.zeros((P, Cs), **f32)
+        dv_acc = torch.zeros((P, 3, Cv), **f32)
+        du_acc = torch.zeros((P, 3, Ov), **f32)
+        dvc = torch.zeros((P, 3, Ov), **f32)
+        dzp_acc = torch.zeros((P, 3, 3), **f32)
+        dzc = torch.zeros((P, 3, 3), **f32)
+        dbeta_perm = torch.zeros((320,), **f32)
+        d = EdgeBlockBwdDesc()
+        d.B, d.N, d.k = B, N, k
+        d.Cs, d.Cv, d.Os, d.Ov = Cs, Cv, Os, Ov
+        d.s, d.v, d.idx, d.zz, d.ut = _p(s), _p(v), _p(idx), _p(zz), _p(ut)
+        d.w_sign, d.w_nz, d.beta_perm, d.w1bt, d.scale1 = _p(w_sign), _p(w_nz), _p(beta_perm), _p(wbt), _p(sc1)
+        d.slot_max, d.slot_min, d.coef, d.gate = _p(slot_max), _p(slot_min), _p(coef), _p(gate)
+        d.gy, d.bcoef, d.gv, d.gconst = _p(gy), _p(bcoef), _p(gv), _p(gconst)
+        d.dn_out, d.x_sign32, d.x_nz32 = _p(dn_out), _p(x_sign), _p(x_nz)
+        d.ds_acc, d.dv_acc, d.du_acc, d.dvc = _p(ds_acc), _p(dv_acc), _p(du_acc), _p(dvc)
+        d.dzp_acc, d.dzc, d.dbeta_perm = _p(dzp_acc), _p(dzc), _p(dbeta_perm)
+        call("svnet_edgeblock_bwd_f32", ctypes.byref(d), _stream())
+
+        # ---- linear1 parameters: GX = dy^T . x_b (MFMA, ternary planes), back to the reference's column order
+        perm = _fused_columns(Cs, Cv, dev)
+        GXp = torch.empty((Os, 320), **f32)
+        gemm(320, Os, E, a_planes=(x_sign, x_nz), B=dn_out, b_rs=Os, b_cs=1, C=GXp, ldc=1, c_cs=320)
+        GX = GXp.index_select(1, perm).contiguous()
+        dW1 = torch.zeros_like(W1)
+        dsc1 = torch.zeros((Os,), **f32)
+        call("svnet_binweight_grad_f32", _p(GX), _p(_f32c(W1)), _p(sc1), Os, 2 * Cs + 6 * Cv, _p(dW1), _p(dsc1), _stream())
+        dbeta1 = dbeta_perm.index_select(0, perm).view(1, -1)
+
+        # ---- point-level backward of the collapsed linear maps (linear2: U|T, v2s frame: Zp|Zq)
+        dUT = torch.cat((du_acc - dvc, dvc), dim=-1).view(3 * P, 2 * Ov)
+        gemm(3 * P, Cv, 2 * Ov, A=dUT, a_rs=2 * Ov, a_cs=1, a_scale=sc22, B=w2c, b_rs=Cv, b_cs=1, b_exact=True, C=dv_acc, ldc=Cv,
+             accumulate=True)
+        GX2c = torch.empty((2 * Ov, Cv), **f32)
+        gemm(2 * Ov, Cv, 3 * P, A=dUT, a_rs=1, a_cs=2 * Ov, B=v, b_rs=Cv, b_cs=1, C=GX2c, ldc=Cv)
+        GX2 = torch.cat((GX2c[:Ov], GX2c[Ov:]), dim=1).contiguous()
+        dW2 = torch.zeros_like(W2)
+        dsc2 = torch.zeros((Ov,), **f32)
+        call("svnet_binweight_grad_f32", _p(GX2), _p(_f32c(W2)), _p(sc2.reshape(-1)), Ov, 2 * Cv, _p(dW2), _p(dsc2), _stream())
+
+        dZZ = torch.cat((dzp_acc - dzc, dzc), dim=-1).view(3 * P, 6)
+        gemm(3 * P, Cv, 6, A=dZZ, a_rs=6, a_cs=1, a_scale=scz2, B=wzz, b_rs=Cv, b_cs=1, C=dv_acc, ldc=Cv, accumulate=True)
+        GXzc = torch.empty((6, Cv), **f32)
+        gemm(6, Cv, 3 * P, A=dZZ, a_rs=1, a_cs=6, B=v, b_rs=Cv, b_cs=1, C=GXzc, ldc=Cv)
+        GXz = torch.cat((GXzc[:3], GXzc[3:]), dim=1).contiguous()
+        dWz = torch.zeros_like(Wz)
+        dscz = torch.zeros((3,), **f32)
+        call("svnet_binweight_grad_f32", _p(GXz), _p(_f32c(Wz)), _p(scz.reshape(-1)), 3, 2 * Cv, _p(dWz), _p(dscz), _stream())
+
+        # forward args: s, v, idx, k, training, Wz, scz, W1, beta1, scale1, g1, b1, rm1, rv1, W2, sc2, g2, b2, rm2, rv2, Wg0, Wg2
+        return (ds_acc.view(B, N, Cs), dv_acc.view(B, N, 3, Cv), None, None, None, dWz, dscz.view_as(scz), dW1, dbeta1,
+                dsc1.view_as(scale1), dg1, db1, None, None, dW2, dsc2.view_as(sc2), dg2, db2, None, None, dWg0, dWg2)
+
+
+_PERM_CACHE = {}
+
+
+def _fused_columns(Cs, Cv, dev):
+    """column of the fused bit order (5 x 64) that holds reference feature f of [s_j-s_i | s_i | s_v (c2*3+jz)]"""
+    key = (Cs, Cv, str(dev))
+    if key not in _PERM_CACHE:
+        f = torch.arange(2 * Cs + 6 * Cv)
+        g = (f - 2 * Cs).clamp(min=0)
+        col = torch.where(f < Cs, f, torch.where(f < 2 * Cs, 64 + f - Cs, 128 + 64 * (g % 3) + g // 3))
+        _PERM_CACHE[key] = col.to(dev)
+    return _PERM_CACHE[key]

@@ -151,6 +151,8 @@ class PendingEdgeBlock:
         b, e = self.block, self.edges
         bn1, bn2 = b.bn1, b.bn2.bn
         training = b.training
+        if not training and torch.is_grad_enabled() and (e.s.requires_grad or any(p.requires_grad for p in b.parameters())):
+            return None            # eval-mode gradients (bare sign(): zero STE gradient) take the layer-wise path
         if training:
             bn1.num_batches_tracked.add_(1)
             bn2.num_batches_tracked.add_(1)

@@ -69,3 +69,22 @@ def test_fused_forward_matches_layerwise_and_oracle(shape, train, hip_device):
     with torch.no_grad():
         os_, ov = sv_ref.svpool(sv_ref.svblock(sv_ref.graph_feature_sv((s, v), k=k), P, "m", True, ctx))
     compare_case(got, {"out0": os_.numpy(), "out1": ov.numpy()}, 1e-4, "fused vs oracle")
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=[str(i) for i in range(len(SHAPES))])
+def test_fused_backward_matches_layerwise(shape, hip_device):
+    """Every gradient of the fused block (recompute-based single edge pass) against autograd through the layer-wise
+    HIP path on identical inputs and upstream gradients."""
+    grads = {}
+    for fuse in (True, False):
+        blk, params, s, v, (in_dims, out_dims, B, N, k) = _make(shape, hip_device, True, "fused_bwd")
+        sd, vd, (os_, ov) = _run(blk, s, v, k, hip_device, fuse, grad=True)
+        rs = C.t("fused_bwd/rs", tuple(os_.shape)).to(hip_device)
+        rv = C.t("fused_bwd/rv", tuple(ov.shape)).to(hip_device)
+        ((os_ * rs).sum() + (ov * rv).sum()).backward()
+        g = {"dx0": sd.grad.cpu().numpy(), "dx1": vd.grad.cpu().numpy()}
+        for n, p in blk.named_parameters():
+            g["d:" + n] = p.grad.cpu().numpy()
+        grads[fuse] = g
+    assert set(grads[True]) == set(grads[False])
+    compare_case(grads[True], grads[False], 1e-3, "fused vs layerwise backward")
