@@ -93,15 +93,14 @@ def main():
         bucket.zero()
         loss = cal_loss(model(x), y)
         loss.backward()
-        return loss
+        return loss.detach()
 
-    # a few eager steps first (allocator warm-up, also what a graph capture needs)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(2):
-            loss = fwd_bwd()
-    torch.cuda.current_stream().wait_stream(side)
+    # a few eager steps first (allocator warm-up).  They run on the SAME stream the capture will use, and no autograd
+    # graph of theirs is kept alive: AccumulateGrad nodes remembered from another stream make the capture fork into a
+    # second stream, and the allocator then re-uses blocks (e.g. the saved neighbour ids) across the fork.
+    for _ in range(2):
+        loss = fwd_bwd()
+        del loss
     torch.cuda.synchronize()
 
     graph = None
@@ -109,7 +108,7 @@ def main():
         try:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                loss = fwd_bwd()
+                fwd_bwd()
         except Exception as e:                                        # capture is an optimisation, not a requirement
             if rank == 0:
                 print("graph capture failed, running eagerly: %r" % (e,), file=sys.stderr)

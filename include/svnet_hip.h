@@ -172,6 +172,7 @@ typedef struct svnet_edgeblock_bwd_desc {
     const float* gconst;         /* [B,2Cs]: dL/d(gate input) / (N*k) */
     float* dn_out; uint32_t* x_sign32; uint32_t* x_nz32;
     float* ds_acc; float* dv_acc; float* du_acc; float* dvc; float* dzp_acc; float* dzc; float* dbeta_perm;
+    int64_t* debug;              /* optional [4]: {count, first bad edge, its idx value, N}; edges with idx outside [0,N) are skipped */
 } svnet_edgeblock_bwd_desc;
 int svnet_edgeblock_wbt_bf16(const uint64_t* w_sign, const uint64_t* w_nz, int64_t Os, uint16_t* wbt, void* stream);
 /* gy = Gs*lrelu'(y) at the pooled edge; red [2*Os], redv [2*Ov], dgate [B,Ov] accumulate (caller zero-fills).      */

@@ -65,6 +65,7 @@ class EdgeBlockBwdDesc(ctypes.Structure):
         ("coef", c_p), ("gate", c_p), ("gy", c_p), ("bcoef", c_p), ("gv", c_p), ("gconst", c_p),
         ("dn_out", c_p), ("x_sign32", c_p), ("x_nz32", c_p),
         ("ds_acc", c_p), ("dv_acc", c_p), ("du_acc", c_p), ("dvc", c_p), ("dzp_acc", c_p), ("dzc", c_p), ("dbeta_perm", c_p),
+        ("debug", c_p),
     ]
 
 

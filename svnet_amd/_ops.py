@@ -629,6 +629,7 @@ class EdgeBlock(torch.autograd.Function):
         d.dn_out, d.x_sign32, d.x_nz32 = _p(dn_out), _p(x_sign), _p(x_nz)
         d.ds_acc, d.dv_acc, d.du_acc, d.dvc = _p(ds_acc), _p(dv_acc), _p(du_acc), _p(dvc)
         d.dzp_acc, d.dzc, d.dbeta_perm = _p(dzp_acc), _p(dzc), _p(dbeta_perm)
+        d.debug = _p(DEBUG_BUFFER)
         call("svnet_edgeblock_bwd_f32", ctypes.byref(d), _stream())
 
         # ---- linear1 parameters: GX = dy^T . x_b (MFMA, ternary planes), back to the reference's column order
@@ -667,6 +668,7 @@ class EdgeBlock(torch.autograd.Function):
 
 
 _PERM_CACHE = {}
+DEBUG_BUFFER = None     # optional int64[4] device tensor: first out-of-range neighbour id seen by the fused backward
 
 
 def _fused_columns(Cs, Cv, dev):

@@ -203,7 +203,16 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_
             const int64_t gp = e / k;
             const int t = (int)(e - gp * k);
             const int64_t b = gp / d.N;
-            const int64_t gj = b * d.N + d.idx[e];
+            const int64_t jloc = d.idx[e];
+            if ((uint64_t)jloc >= (uint64_t)d.N) {  // corrupted neighbour id: never dereference it
+                if (d.debug && lane == 0) {
+                    if (atomicAdd(reinterpret_cast<unsigned long long*>(d.debug), 1ull) == 0ull) { d.debug[1] = e; d.debug[2] = jloc; d.debug[3] = d.N; }
+                }
+                for (int o = lane; o < Os; o += 64) dnl[r * DNS + o] = 0.f;
+                if (lane < NW) { pl[(0 * TE + r) * NW + lane] = 0ull; pl[(1 * TE + r) * NW + lane] = 0ull; pl[(2 * TE + r) * NW + lane] = 0ull; }
+                continue;
+            }
+            const int64_t gj = b * d.N + jloc;
             if (gp != cur_p) {
                 if (cur_p >= 0 && o_lane) {
 #pragma unroll
@@ -369,23 +378,25 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_
         int64_t cur_p = -1;
         float csum = 0.f;                       // centre part of ds for the current point (lane c < Cs)
         float cvd[3] = {0.f, 0.f, 0.f};         // centre part of dv  (lanes < 2Cv: diff lanes carry -sum, centre lanes +sum)
-        float czq[9];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) czq[q] = 0.f;
+        float czq0 = 0.f, czq1 = 0.f, czq2 = 0.f, czq3 = 0.f, czq4 = 0.f, czq5 = 0.f, czq6 = 0.f, czq7 = 0.f, czq8 = 0.f;
 
-        auto flush_point = [&](int64_t p) {
-            if (s_lane) atomicAdd(&d.ds_acc[p * Cs + lane], csum);
-            if (v2_lane) {
-#pragma unroll
-                for (int dd = 0; dd < 3; ++dd) atomicAdd(&d.dv_acc[(p * 3 + dd) * Cv + cm], cvd[dd]);
-            }
-            if (lane < 9) {
-                float val = czq[0];
-#pragma unroll
-                for (int q = 1; q < 9; ++q) val = (lane == q) ? czq[q] : val;
-                atomicAdd(&d.dzc[p * 9 + lane], val);
-            }
-        };
+// (kept as a macro: a by-reference lambda forces the per-point accumulators into scratch memory)
+#define SVNET_FLUSH_POINT(p)                                                                                     \
+    do {                                                                                                         \
+        if (s_lane) atomicAdd(&d.ds_acc[(p) * Cs + lane], csum);                                                 \
+        if (v2_lane) {                                                                                           \
+            atomicAdd(&d.dv_acc[((p) * 3 + 0) * Cv + cm], cvd[0]);                                               \
+            atomicAdd(&d.dv_acc[((p) * 3 + 1) * Cv + cm], cvd[1]);                                               \
+            atomicAdd(&d.dv_acc[((p) * 3 + 2) * Cv + cm], cvd[2]);                                               \
+        }                                                                                                        \
+        if (lane < 9) {                                                                                          \
+            float val_ = czq0;                                                                                   \
+            val_ = (lane == 1) ? czq1 : val_; val_ = (lane == 2) ? czq2 : val_; val_ = (lane == 3) ? czq3 : val_; \
+            val_ = (lane == 4) ? czq4 : val_; val_ = (lane == 5) ? czq5 : val_; val_ = (lane == 6) ? czq6 : val_; \
+            val_ = (lane == 7) ? czq7 : val_; val_ = (lane == 8) ? czq8 : val_;                                   \
+            atomicAdd(&d.dzc[(p) * 9 + lane], val_);                                                             \
+        }                                                                                                        \
+    } while (0)
 
         for (int rr = 0; rr < TE / 4; ++rr) {
             const int r = wave * (TE / 4) + rr;
@@ -393,14 +404,15 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_
             if (e >= E) continue;
             const int64_t gp = e / k;
             const int64_t b = gp / d.N;
-            const int64_t gj = b * d.N + d.idx[e];
+            const int64_t jloc = d.idx[e];
+            if ((uint64_t)jloc >= (uint64_t)d.N) continue;
+            const int64_t gj = b * d.N + jloc;
             if (gp != cur_p) {
-                if (cur_p >= 0) flush_point(cur_p);
+                if (cur_p >= 0) SVNET_FLUSH_POINT(cur_p);
                 cur_p = gp;
                 csum = 0.f;
                 cvd[0] = cvd[1] = cvd[2] = 0.f;
-#pragma unroll
-                for (int q = 0; q < 9; ++q) czq[q] = 0.f;
+                czq0 = czq1 = czq2 = czq3 = czq4 = czq5 = czq6 = czq7 = czq8 = 0.f;
             }
             const float* row = dxl + r * DXS;
             const float gx0 = s_lane ? row[lane] : 0.f;            // d/d(s_j - s_i) through the binarization
@@ -431,7 +443,6 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_
 #pragma unroll
                 for (int jz = 0; jz < 3; ++jz) z[dd][jz] = zj[jz] + (zi[3 + jz] - zi[jz]);
             }
-            float dz[9];
 #pragma unroll
             for (int dd = 0; dd < 3; ++dd) {
                 const float dve = gxv[0] * z[dd][0] + gxv[1] * z[dd][1] + gxv[2] * z[dd][2];
@@ -441,19 +452,21 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_
                 } else if (v2_lane) {
                     cvd[dd] += dve;
                 }
-#pragma unroll
-                for (int jz = 0; jz < 3; ++jz) dz[dd * 3 + jz] = wave_sum(gxv[jz] * ve[dd]);
             }
-#pragma unroll
-            for (int q = 0; q < 9; ++q) czq[q] += dz[q];
+            const float dz0 = wave_sum(gxv[0] * ve[0]), dz1 = wave_sum(gxv[1] * ve[0]), dz2 = wave_sum(gxv[2] * ve[0]);
+            const float dz3 = wave_sum(gxv[0] * ve[1]), dz4 = wave_sum(gxv[1] * ve[1]), dz5 = wave_sum(gxv[2] * ve[1]);
+            const float dz6 = wave_sum(gxv[0] * ve[2]), dz7 = wave_sum(gxv[1] * ve[2]), dz8 = wave_sum(gxv[2] * ve[2]);
+            czq0 += dz0; czq1 += dz1; czq2 += dz2; czq3 += dz3; czq4 += dz4; czq5 += dz5; czq6 += dz6; czq7 += dz7; czq8 += dz8;
             if (lane < 9) {
-                float val = dz[0];
-#pragma unroll
-                for (int q = 1; q < 9; ++q) val = (lane == q) ? dz[q] : val;
+                float val = dz0;
+                val = (lane == 1) ? dz1 : val; val = (lane == 2) ? dz2 : val; val = (lane == 3) ? dz3 : val;
+                val = (lane == 4) ? dz4 : val; val = (lane == 5) ? dz5 : val; val = (lane == 6) ? dz6 : val;
+                val = (lane == 7) ? dz7 : val; val = (lane == 8) ? dz8 : val;
                 atomicAdd(&d.dzp_acc[gj * 9 + lane], val);
             }
         }
-        if (cur_p >= 0) flush_point(cur_p);
+        if (cur_p >= 0) SVNET_FLUSH_POINT(cur_p);
+#undef SVNET_FLUSH_POINT
         if (s_lane) {
             atomicAdd(&d.dbeta_perm[lane], dbd);
             atomicAdd(&d.dbeta_perm[64 + lane], dbc);
