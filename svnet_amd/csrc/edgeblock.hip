@@ -71,7 +71,14 @@ template <int OP>
 __global__ __launch_bounds__(256) void edgeblock_fwd_kernel(FwdArgs fa) {
     const svnet_edgeblock_desc& d = fa.d;
     const int lane = threadIdx.x & 63;
-    const int64_t wave_g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // XCD-aware order: workgroups b and b+8 share an XCD, so XCD x walks the clouds x, x+8, ... one after the other and
+    // a cloud's point tables stay in that XCD's L2 while its edges are processed
+    int64_t blk = blockIdx.x;
+    if ((d.B & 7) == 0 && (fa.waves_per_cloud & 3) == 0) {
+        const int64_t bpc = fa.waves_per_cloud >> 2, xcd = blk & 7, slot = blk >> 3;
+        blk = ((slot / bpc) * 8 + xcd) * bpc + (slot % bpc);
+    }
+    const int64_t wave_g = blk * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // uniform: scalar loads / SGPR addressing
     const int64_t b = wave_g / fa.waves_per_cloud;
     if (b >= d.B) return;  // wave-uniform, no barriers in this kernel
     const int wi = (int)(wave_g - b * fa.waves_per_cloud);
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(256) void edgeblock_fwd_kernel(FwdArgs fa) {
 
     for (int p = p_begin; p < p_end; ++p) {
         const int64_t gp = b * d.N + p;
-        const float s_i = s_lane ? d.s[gp * Cs + lane] : 0.f;
+        const float s_i = s_lane ? d.s[gp * Cs + min(lane, Cs - 1)] : 0.f;
         gs_cen += s_i;
         const float tc = s_i + bc;
         const uint64_t csg = __ballot(s_lane && tc > 0.f), cnz = __ballot(s_lane && tc != 0.f);
@@ -131,21 +138,38 @@ __global__ __launch_bounds__(256) void edgeblock_fwd_kernel(FwdArgs fa) {
         for (int op = 0; op < OP; ++op) { nmax[op] = INT_MIN; nmin[op] = INT_MAX; smax[op] = 0; smin[op] = 0; }
         float av[3] = {0.f, 0.f, 0.f}, avn[3] = {0.f, 0.f, 0.f};
 
+        // neighbour rows are loaded one edge ahead (all lanes, clamped channel index: no exec-masked branches)
+        const int ls = min(lane, Cs - 1), ld = min(lane, Cv - 1), lo = min(lane, Ov - 1);
+        float n_sj, n_vj0, n_vj1, n_vj2, n_u0, n_u1, n_u2, n_z[9];
+#define SVNET_LOAD_NBR(T)                                                                   \
+    do {                                                                                    \
+        const int64_t gj_ = b * d.N + d.idx[gp * k + (T)];                                  \
+        n_sj = d.s[gj_ * Cs + ls];                                                          \
+        n_vj0 = d.v[(gj_ * 3 + 0) * Cv + ld]; n_vj1 = d.v[(gj_ * 3 + 1) * Cv + ld]; n_vj2 = d.v[(gj_ * 3 + 2) * Cv + ld]; \
+        n_u0 = d.ut[(gj_ * 3 + 0) * 2 * Ov + lo]; n_u1 = d.ut[(gj_ * 3 + 1) * 2 * Ov + lo]; n_u2 = d.ut[(gj_ * 3 + 2) * 2 * Ov + lo]; \
+        const float* zr_ = d.zz + gj_ * 18;                                                 \
+        n_z[0] = zr_[0]; n_z[1] = zr_[1]; n_z[2] = zr_[2]; n_z[3] = zr_[6]; n_z[4] = zr_[7]; n_z[5] = zr_[8];              \
+        n_z[6] = zr_[12]; n_z[7] = zr_[13]; n_z[8] = zr_[14];                               \
+    } while (0)
+        SVNET_LOAD_NBR(0);
         for (int t = 0; t < k; ++t) {
-            const int64_t gj = b * d.N + d.idx[gp * k + t];
-            const float sd = (s_lane ? d.s[gj * Cs + lane] : 0.f) - s_i;
+            const float sj = n_sj, vj0 = n_vj0, vj1 = n_vj1, vj2 = n_vj2, u0 = n_u0, u1 = n_u1, u2 = n_u2;
+            float zj[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) zj[q] = n_z[q];
+            if (t + 1 < k) SVNET_LOAD_NBR(t + 1);
+            const float sd = s_lane ? (sj - s_i) : 0.f;
             gs_diff += sd;
             const float td = sd + bd;
             const uint64_t dsg = __ballot(s_lane && td > 0.f), dnz = __ballot(s_lane && td != 0.f);
             float ve[3], z[3][3];
+            ve[0] = diff_lane ? (vj0 - vi[0]) : vi[0];
+            ve[1] = diff_lane ? (vj1 - vi[1]) : vi[1];
+            ve[2] = diff_lane ? (vj2 - vi[2]) : vi[2];
 #pragma unroll
-            for (int dd = 0; dd < 3; ++dd) {
-                const float vj = diff_lane ? d.v[(gj * 3 + dd) * Cv + lane] : 0.f;
-                ve[dd] = diff_lane ? (vj - vi[dd]) : vi[dd];
-                const float* zrow = d.zz + (gj * 3 + dd) * 6;
+            for (int dd = 0; dd < 3; ++dd)
 #pragma unroll
-                for (int jz = 0; jz < 3; ++jz) z[dd][jz] = zrow[jz] + zi[dd][jz];
-            }
+                for (int jz = 0; jz < 3; ++jz) z[dd][jz] = zj[dd * 3 + jz] + zi[dd][jz];
             uint64_t vsg[3], vnz[3];
 #pragma unroll
             for (int jz = 0; jz < 3; ++jz) {
@@ -163,16 +187,17 @@ __global__ __launch_bounds__(256) void edgeblock_fwd_kernel(FwdArgs fa) {
                 sn[op] += n;
                 sn2[op] += n * n;
             }
-            float vp[3];
-#pragma unroll
-            for (int dd = 0; dd < 3; ++dd) vp[dd] = (o_lane ? d.ut[(gj * 3 + dd) * 2 * Ov + lane] : 0.f) + ub[dd];
-            const float nn = sqrtf(vp[0] * vp[0] + vp[1] * vp[1] + vp[2] * vp[2]) + VEPS;
-            const float inv = 1.f / nn;
-#pragma unroll
-            for (int dd = 0; dd < 3; ++dd) { av[dd] += vp[dd]; avn[dd] += vp[dd] * inv; }
-            sv1 += (double)nn;
-            sv2 += (double)nn * (double)nn;
+            if (o_lane) {
+                const float vp0 = u0 + ub[0], vp1 = u1 + ub[1], vp2 = u2 + ub[2];
+                const float nn = sqrtf(vp0 * vp0 + vp1 * vp1 + vp2 * vp2) + VEPS;
+                const float inv = 1.f / nn;
+                av[0] += vp0; av[1] += vp1; av[2] += vp2;
+                avn[0] += vp0 * inv; avn[1] += vp1 * inv; avn[2] += vp2 * inv;
+                sv1 += (double)nn;
+                sv2 += (double)nn * (double)nn;
+            }
         }
+#undef SVNET_LOAD_NBR
         const float invk = 1.f / (float)k;
 #pragma unroll
         for (int op = 0; op < OP; ++op) {

@@ -14,9 +14,13 @@
 //   phase C (lanes = channels): beta / s / v2s backward, scatter-add to the point tables.
 // The weight gradient GX = dy^T . x_b is left to mfma_tn_kernel (gemm_mfma.hip) on the dn_out + planes this kernel
 // writes (4 B + 0.25 B per edge-channel instead of the 4 B fp32 input the layer-wise path keeps).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
+
+#define ATOMIC_ADD(p, v) do { if (MODE != 1) atomicAdd((p), (v)); else asm volatile("" :: "v"(v)); } while (0)
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -145,18 +149,87 @@ __global__ void edgeblock_bwd_coeffs_kernel(const float* __restrict__ red, const
 }
 
 // ---------------------------------------------------------------------------------------------- edge pass
-template <int OP>
+// Everything one lane needs for one edge row.  The row index is wave-uniform (readfirstlane'd wave id), so gp / gj /
+// the zz rows go through scalar loads and SGPR-based addressing.
+struct EdgeIn {
+    int64_t gp, gj, b;
+    int t;
+    bool valid;
+    float si, sj;                                 // lane c < Cs
+    float vi0, vi1, vi2, vj0, vj1, vj2;           // lane c2 < 2Cv (vj: diff lanes only)
+    float z0, z1, z2, z3, z4, z5, z6, z7, z8;     // z[d*3+jz] = Zp_j - Zp_i + Zq_i
+    float ui0, ui1, ui2, uj0, uj1, uj2;           // lane c' < Ov: ui = T_i - U_i, uj = U_j
+};
+
+__device__ __forceinline__ void load_edge(const svnet_edgeblock_bwd_desc& d, int64_t e, int64_t E, int lane, bool s_lane,
+                                          bool v2_lane, bool diff_lane, bool o_lane, int cm, bool want_u, EdgeIn& in) {
+    const int Cs = d.Cs, Cv = d.Cv, Ov = d.Ov, k = (int)d.k;
+    in.valid = e < E;
+    if (!in.valid) return;
+    in.gp = e / k;
+    in.t = (int)(e - in.gp * k);
+    in.b = in.gp / d.N;
+    const int64_t jloc = d.idx[e];
+    if ((uint64_t)jloc >= (uint64_t)d.N) {  // corrupted neighbour id: never dereference it
+        if (d.debug && lane == 0) {
+            if (atomicAdd(reinterpret_cast<unsigned long long*>(d.debug), 1ull) == 0ull) { d.debug[1] = e; d.debug[2] = jloc; d.debug[3] = d.N; }
+        }
+        in.valid = false;
+        return;
+    }
+    in.gj = in.b * d.N + jloc;
+    const int64_t gp = in.gp, gj = in.gj;
+    // clamped lane indices: every lane issues every load (no exec-masked branches, loads go out back to back);
+    // lanes outside a channel range read a valid neighbour element that is masked where it is consumed
+    const int ls = min(lane, Cs - 1), ld = min(lane, Cv - 1), lc = v2_lane ? cm : 0;
+    in.si = d.s[gp * Cs + ls];
+    in.sj = d.s[gj * Cs + ls];
+    in.vi0 = d.v[(gp * 3 + 0) * Cv + lc];
+    in.vi1 = d.v[(gp * 3 + 1) * Cv + lc];
+    in.vi2 = d.v[(gp * 3 + 2) * Cv + lc];
+    in.vj0 = d.v[(gj * 3 + 0) * Cv + ld];
+    in.vj1 = d.v[(gj * 3 + 1) * Cv + ld];
+    in.vj2 = d.v[(gj * 3 + 2) * Cv + ld];
+    const float* zi = d.zz + gp * 18;
+    const float* zj = d.zz + gj * 18;
+    in.z0 = zj[0] + (zi[3] - zi[0]);    in.z1 = zj[1] + (zi[4] - zi[1]);    in.z2 = zj[2] + (zi[5] - zi[2]);
+    in.z3 = zj[6] + (zi[9] - zi[6]);    in.z4 = zj[7] + (zi[10] - zi[7]);   in.z5 = zj[8] + (zi[11] - zi[8]);
+    in.z6 = zj[12] + (zi[15] - zi[12]); in.z7 = zj[13] + (zi[16] - zi[13]); in.z8 = zj[14] + (zi[17] - zi[14]);
+    if (want_u) {
+        const float* ui = d.ut + gp * 6 * Ov;
+        const float* uj = d.ut + gj * 6 * Ov;
+        const int lo = min(lane, Ov - 1);
+        in.ui0 = ui[0 * 2 * Ov + Ov + lo] - ui[0 * 2 * Ov + lo];
+        in.ui1 = ui[1 * 2 * Ov + Ov + lo] - ui[1 * 2 * Ov + lo];
+        in.ui2 = ui[2 * 2 * Ov + Ov + lo] - ui[2 * 2 * Ov + lo];
+        in.uj0 = uj[0 * 2 * Ov + lo];
+        in.uj1 = uj[1 * 2 * Ov + lo];
+        in.uj2 = uj[2 * 2 * Ov + lo];
+    }
+}
+
+template <int OP, int MODE>  // MODE: 0 = product; 1..3 = timing-only ablations (SVNET_BWD_MODE), wrong results
 __global__ __launch_bounds__(256) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_desc d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int Cs = d.Cs, Cv = d.Cv, Os = d.Os, Ov = d.Ov, k = (int)d.k;
+    const int Cs = d.Cs, Cv = d.Cv, Os = d.Os, Ov = d.Ov;
     const int DNS = Os + 4;
     float* dnl = reinterpret_cast<float*>(smem);                    // [TE][DNS]   dL/dn = dy_pre*scale
     float* dxl = dnl + TE * DNS;                                     // [TE][DXS]   masked dx_b
     uint64_t* pl = reinterpret_cast<uint64_t*>(dxl + TE * DXS);      // [3][TE][NW] sign | nz | ste (row-major words)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // uniform: scalar loads / SGPR addressing
     const int64_t E = d.B * d.N * d.k;
-    const int64_t e0 = (int64_t)blockIdx.x * TE;
+    // XCD-aware tile order: workgroups b and b+8 share an XCD (round-robin dispatch), so give XCD x the clouds
+    // x, x+8, ... one after the other: a cloud's point tables (~1.6 MB) then live in that XCD's 4 MiB L2
+    int64_t tile = blockIdx.x;
+    const int64_t tpc = (d.N * d.k) / TE;                            // tiles per cloud
+    if ((d.B & 7) == 0 && tpc * TE == d.N * d.k) {
+        const int64_t xcd = tile & 7, slot = tile >> 3;
+        tile = ((slot / tpc) * 8 + xcd) * tpc + (slot % tpc);
+    }
+    const int64_t e0 = tile * TE;
+    const int64_t ew = e0 + wave * (TE / 4);                          // first edge row of this wave
 
     const float* A1 = d.coef; const float* MY = d.coef + 2 * Os; const float* IY = d.coef + 3 * Os;
     const float* Av = d.coef + 4 * Os; const float* Bv = Av + Ov;
@@ -166,9 +239,7 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_
     const bool s_lane = lane < Cs, v2_lane = lane < 2 * Cv, diff_lane = lane < Cv, o_lane = lane < Ov;
     const int cm = diff_lane ? lane : lane - Cv;
     const float bd = d.beta_perm[lane], bc = d.beta_perm[64 + lane];
-    float bv[3];
-#pragma unroll
-    for (int jz = 0; jz < 3; ++jz) bv[jz] = d.beta_perm[128 + 64 * jz + lane];
+    const float bv0 = d.beta_perm[128 + lane], bv1 = d.beta_perm[192 + lane], bv2 = d.beta_perm[256 + lane];
 
     // ================= phase A =================
     {
@@ -188,65 +259,50 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_
         }
         const float avc = o_lane ? Av[lane] : 0.f, bvc = o_lane ? Bv[lane] : 0.f;
         const float c0 = o_lane ? C0[lane] : 0.f, c1 = o_lane ? C1[lane] : 0.f;
-        const float invk = 1.f / (float)k;
+        const float invk = 1.f / (float)d.k;
 
         int64_t cur_p = -1;
-        float cvsum[3] = {0.f, 0.f, 0.f};   // centre sum of dv' for the current point
+        float cv0 = 0.f, cv1 = 0.f, cv2 = 0.f;   // centre sum of dv' for the current point
+        EdgeIn in, nx;
+        load_edge(d, ew, E, lane, s_lane, v2_lane, diff_lane, o_lane, cm, true, in);
+#pragma unroll 1
         for (int rr = 0; rr < TE / 4; ++rr) {
             const int r = wave * (TE / 4) + rr;
-            const int64_t e = e0 + r;
-            if (e >= E) {  // wave-uniform: rows past the end contribute zeros
+            // issue the NEXT edge's loads before this edge's atomics: vmcnt retires in order, so loads queued behind
+            // atomics would expose the full atomic latency on every edge
+            nx.valid = false;
+            if (rr + 1 < TE / 4) load_edge(d, ew + rr + 1, E, lane, s_lane, v2_lane, diff_lane, o_lane, cm, true, nx);
+            if (!in.valid) {  // wave-uniform: rows past the end (or corrupted ids) contribute zeros
                 for (int o = lane; o < Os; o += 64) dnl[r * DNS + o] = 0.f;
                 if (lane < NW) { pl[(0 * TE + r) * NW + lane] = 0ull; pl[(1 * TE + r) * NW + lane] = 0ull; pl[(2 * TE + r) * NW + lane] = 0ull; }
+                in = nx;
                 continue;
             }
-            const int64_t gp = e / k;
-            const int t = (int)(e - gp * k);
-            const int64_t b = gp / d.N;
-            const int64_t jloc = d.idx[e];
-            if ((uint64_t)jloc >= (uint64_t)d.N) {  // corrupted neighbour id: never dereference it
-                if (d.debug && lane == 0) {
-                    if (atomicAdd(reinterpret_cast<unsigned long long*>(d.debug), 1ull) == 0ull) { d.debug[1] = e; d.debug[2] = jloc; d.debug[3] = d.N; }
-                }
-                for (int o = lane; o < Os; o += 64) dnl[r * DNS + o] = 0.f;
-                if (lane < NW) { pl[(0 * TE + r) * NW + lane] = 0ull; pl[(1 * TE + r) * NW + lane] = 0ull; pl[(2 * TE + r) * NW + lane] = 0ull; }
-                continue;
-            }
-            const int64_t gj = b * d.N + jloc;
+            const int64_t e = ew + rr, gp = in.gp, gj = in.gj;
             if (gp != cur_p) {
                 if (cur_p >= 0 && o_lane) {
-#pragma unroll
-                    for (int dd = 0; dd < 3; ++dd) atomicAdd(&d.dvc[(cur_p * 3 + dd) * Ov + lane], cvsum[dd]);
+                    ATOMIC_ADD(&d.dvc[(cur_p * 3 + 0) * Ov + lane], cv0);
+                    ATOMIC_ADD(&d.dvc[(cur_p * 3 + 1) * Ov + lane], cv1);
+                    ATOMIC_ADD(&d.dvc[(cur_p * 3 + 2) * Ov + lane], cv2);
                 }
                 cur_p = gp;
-                cvsum[0] = cvsum[1] = cvsum[2] = 0.f;
+                cv0 = cv1 = cv2 = 0.f;
             }
             // ---- recompute the edge row (same arithmetic as edgeblock_fwd_kernel)
-            const float s_i = s_lane ? d.s[gp * Cs + lane] : 0.f;
-            const float tc = s_i + bc;
-            const float sd = (s_lane ? d.s[gj * Cs + lane] : 0.f) - s_i;
-            const float td = sd + bd;
+            const float tc = in.si + bc;
+            const float td = (in.sj - in.si) + bd;
             uint64_t xs[NW], xz[NW], xt[NW];
             xs[1] = __ballot(s_lane && tc > 0.f); xz[1] = __ballot(s_lane && tc != 0.f); xt[1] = __ballot(s_lane && fabsf(tc) <= 1.2f);
             xs[0] = __ballot(s_lane && td > 0.f); xz[0] = __ballot(s_lane && td != 0.f); xt[0] = __ballot(s_lane && fabsf(td) <= 1.2f);
-            float ve[3], z[3][3];
-#pragma unroll
-            for (int dd = 0; dd < 3; ++dd) {
-                const float vi = v2_lane ? d.v[(gp * 3 + dd) * Cv + cm] : 0.f;
-                const float vj = diff_lane ? d.v[(gj * 3 + dd) * Cv + lane] : 0.f;
-                ve[dd] = diff_lane ? (vj - vi) : vi;
-                const float* zi = d.zz + (gp * 3 + dd) * 6;
-                const float* zj = d.zz + (gj * 3 + dd) * 6;
-#pragma unroll
-                for (int jz = 0; jz < 3; ++jz) z[dd][jz] = zj[jz] + (zi[3 + jz] - zi[jz]);
-            }
-#pragma unroll
-            for (int jz = 0; jz < 3; ++jz) {
-                const float tv = ve[0] * z[0][jz] + ve[1] * z[1][jz] + ve[2] * z[2][jz] + bv[jz];
-                xs[2 + jz] = __ballot(v2_lane && tv > 0.f);
-                xz[2 + jz] = __ballot(v2_lane && tv != 0.f);
-                xt[2 + jz] = __ballot(v2_lane && fabsf(tv) <= 1.2f);
-            }
+            const float ve0 = diff_lane ? (in.vj0 - in.vi0) : (v2_lane ? in.vi0 : 0.f);
+            const float ve1 = diff_lane ? (in.vj1 - in.vi1) : (v2_lane ? in.vi1 : 0.f);
+            const float ve2 = diff_lane ? (in.vj2 - in.vi2) : (v2_lane ? in.vi2 : 0.f);
+            const float tv0 = ve0 * in.z0 + ve1 * in.z3 + ve2 * in.z6 + bv0;
+            const float tv1 = ve0 * in.z1 + ve1 * in.z4 + ve2 * in.z7 + bv1;
+            const float tv2 = ve0 * in.z2 + ve1 * in.z5 + ve2 * in.z8 + bv2;
+            xs[2] = __ballot(v2_lane && tv0 > 0.f); xz[2] = __ballot(v2_lane && tv0 != 0.f); xt[2] = __ballot(v2_lane && fabsf(tv0) <= 1.2f);
+            xs[3] = __ballot(v2_lane && tv1 > 0.f); xz[3] = __ballot(v2_lane && tv1 != 0.f); xt[3] = __ballot(v2_lane && fabsf(tv1) <= 1.2f);
+            xs[4] = __ballot(v2_lane && tv2 > 0.f); xz[4] = __ballot(v2_lane && tv2 != 0.f); xt[4] = __ballot(v2_lane && fabsf(tv2) <= 1.2f);
             if (lane < NW) {
                 uint64_t a = xs[0], bq = xz[0], cq = xt[0];
 #pragma unroll
@@ -266,7 +322,7 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_
 #pragma unroll
                     for (int w = 0; w < NW; ++w) n += tdot(xs[w], xz[w], wsg[op][w], wnz[op][w]);
                     const int slot = (a1[op] >= 0.f) ? d.slot_max[gp * Os + o] : d.slot_min[gp * Os + o];
-                    const float g = (slot == t) ? d.gy[gp * Os + o] : 0.f;
+                    const float g = (slot == in.t) ? d.gy[gp * Os + o] : 0.f;
                     const float xh = (sc1[op] * (float)n - my[op]) * iy[op];
                     const float dyp = cs[op] * (g - m1[op] - xh * m2[op]);
                     d.dn_out[e * Os + o] = dyp;
@@ -275,34 +331,32 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_
             }
             // ---- vector path: v' = U_j - U_i + T_i, out = gate * mean_k v'*(Av + Bv/n')
             if (o_lane) {
-                float vp[3], ge[3];
-                const float gt = d.gate[b * Ov + lane] * invk;
-#pragma unroll
-                for (int dd = 0; dd < 3; ++dd) {
-                    const float* ui = d.ut + (gp * 3 + dd) * 2 * Ov;
-                    vp[dd] = d.ut[(gj * 3 + dd) * 2 * Ov + lane] + (ui[Ov + lane] - ui[lane]);
-                    ge[dd] = d.gv[(gp * 3 + dd) * Ov + lane] * gt;
-                }
-                const float nv = sqrtf(vp[0] * vp[0] + vp[1] * vp[1] + vp[2] * vp[2]);
+                const float gt = d.gate[in.b * Ov + lane] * invk;
+                const float vp0 = in.uj0 + in.ui0, vp1 = in.uj1 + in.ui1, vp2 = in.uj2 + in.ui2;
+                const float ge0 = d.gv[(gp * 3 + 0) * Ov + lane] * gt, ge1 = d.gv[(gp * 3 + 1) * Ov + lane] * gt,
+                            ge2 = d.gv[(gp * 3 + 2) * Ov + lane] * gt;
+                const float nv = sqrtf(vp0 * vp0 + vp1 * vp1 + vp2 * vp2);
                 const float nn = nv + VEPS;
                 const float q = avc + bvc / nn;
-                const float gdot = ge[0] * vp[0] + ge[1] * vp[1] + ge[2] * vp[2];
+                const float gdot = ge0 * vp0 + ge1 * vp1 + ge2 * vp2;
                 const float dnn = -gdot * bvc / (nn * nn) + c0 + c1 * nn;
                 const float kk = nv > 0.f ? dnn / nv : 0.f;
-#pragma unroll
-                for (int dd = 0; dd < 3; ++dd) {
-                    const float dvp = ge[dd] * q + kk * vp[dd];
-                    atomicAdd(&d.du_acc[(gj * 3 + dd) * Ov + lane], dvp);
-                    cvsum[dd] += dvp;
-                }
+                const float d0 = ge0 * q + kk * vp0, d1 = ge1 * q + kk * vp1, d2 = ge2 * q + kk * vp2;
+                ATOMIC_ADD(&d.du_acc[(gj * 3 + 0) * Ov + lane], d0);
+                ATOMIC_ADD(&d.du_acc[(gj * 3 + 1) * Ov + lane], d1);
+                ATOMIC_ADD(&d.du_acc[(gj * 3 + 2) * Ov + lane], d2);
+                cv0 += d0; cv1 += d1; cv2 += d2;
             }
+            in = nx;
         }
         if (cur_p >= 0 && o_lane) {
-#pragma unroll
-            for (int dd = 0; dd < 3; ++dd) atomicAdd(&d.dvc[(cur_p * 3 + dd) * Ov + lane], cvsum[dd]);
+            ATOMIC_ADD(&d.dvc[(cur_p * 3 + 0) * Ov + lane], cv0);
+            ATOMIC_ADD(&d.dvc[(cur_p * 3 + 1) * Ov + lane], cv1);
+            ATOMIC_ADD(&d.dvc[(cur_p * 3 + 2) * Ov + lane], cv2);
         }
     }
     __syncthreads();
+    if (MODE == 2) return;
 
     // ---- ternary planes of this tile -> row-sliced 32-bit halves (rows = the tile's 32 edges)
     {
@@ -332,27 +386,38 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_
         for (int q = 0; q < 3; ++q)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
-        for (int ks = 0; ks < nks; ++ks) {
-            float x[8];
-            const int kk = ks * 16 + 8 * h;
+        // all B fragments of this wave's column tiles up front (<= 8 k-steps x 3 tiles x 4 VGPRs): one exposed
+        // L2 latency instead of one per k-step
+        bf16x8 bfr[8][3];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = (kk + j < Os) ? dnl[r * DNS + kk + j] : 0.f;
-            bf16x8 fh, fm, fl;
-            split3_frag(x, fh, fm, fl);
+        for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                const int ct = wave + 4 * q;
-                if (ct < NCOL / 32) {  // wave-uniform
-                    bf16x8 bfr;
-                    if (kk + 8 <= Os) {
-                        bfr = wbt[((int64_t)(ct * 32 + r) * Os + kk) >> 3];
-                    } else {
+                const int ct = wave + 4 * q, kk = ks * 16 + 8 * h;
+                if (ks < nks && ct < NCOL / 32 && kk + 8 <= Os) {
+                    bfr[ks][q] = wbt[((int64_t)(ct * 32 + r) * Os + kk) >> 3];
+                } else {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) bfr[j] = bf16_from_bits(0);
+                    for (int j = 0; j < 8; ++j) bfr[ks][q][j] = bf16_from_bits(0);
+                }
+            }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            if (ks < nks) {
+                float x[8];
+                const int kk = ks * 16 + 8 * h;
+                const float4 x0 = *reinterpret_cast<const float4*>(&dnl[r * DNS + kk]);      // DNS % 4 == 0, kk % 8 == 0
+                const float4 x1 = *reinterpret_cast<const float4*>(&dnl[r * DNS + kk + 4]);  // Os % 8 == 0: no ragged k
+                x[0] = x0.x; x[1] = x0.y; x[2] = x0.z; x[3] = x0.w; x[4] = x1.x; x[5] = x1.y; x[6] = x1.z; x[7] = x1.w;
+                bf16x8 fh, fm, fl;
+                split3_frag(x, fh, fm, fl);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    if (wave + 4 * q < NCOL / 32) {  // wave-uniform
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, bfr[ks][q], acc[q], 0, 0, 0);
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fm, bfr[ks][q], acc[q], 0, 0, 0);
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, bfr[ks][q], acc[q], 0, 0, 0);
                     }
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, bfr, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fm, bfr, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, bfr, acc[q], 0, 0, 0);
                 }
             }
         }
@@ -371,109 +436,98 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_
         }
     }
     __syncthreads();
+    if (MODE == 3) return;
 
     // ================= phase C: scatter the input gradients =================
     {
-        float dbd = 0.f, dbc = 0.f, dbv[3] = {0.f, 0.f, 0.f};
+        float dbd = 0.f, dbc = 0.f, dbv0 = 0.f, dbv1 = 0.f, dbv2 = 0.f;
         int64_t cur_p = -1;
-        float csum = 0.f;                       // centre part of ds for the current point (lane c < Cs)
-        float cvd[3] = {0.f, 0.f, 0.f};         // centre part of dv  (lanes < 2Cv: diff lanes carry -sum, centre lanes +sum)
+        float csum = 0.f;                           // centre part of ds for the current point (lane c < Cs)
+        float cvd0 = 0.f, cvd1 = 0.f, cvd2 = 0.f;   // centre part of dv (diff lanes carry -sum, centre lanes +sum)
         float czq0 = 0.f, czq1 = 0.f, czq2 = 0.f, czq3 = 0.f, czq4 = 0.f, czq5 = 0.f, czq6 = 0.f, czq7 = 0.f, czq8 = 0.f;
 
-// (kept as a macro: a by-reference lambda forces the per-point accumulators into scratch memory)
-#define SVNET_FLUSH_POINT(p)                                                                                     \
-    do {                                                                                                         \
-        if (s_lane) atomicAdd(&d.ds_acc[(p) * Cs + lane], csum);                                                 \
-        if (v2_lane) {                                                                                           \
-            atomicAdd(&d.dv_acc[((p) * 3 + 0) * Cv + cm], cvd[0]);                                               \
-            atomicAdd(&d.dv_acc[((p) * 3 + 1) * Cv + cm], cvd[1]);                                               \
-            atomicAdd(&d.dv_acc[((p) * 3 + 2) * Cv + cm], cvd[2]);                                               \
-        }                                                                                                        \
-        if (lane < 9) {                                                                                          \
-            float val_ = czq0;                                                                                   \
+// (a macro: a by-reference lambda forces the per-point accumulators into scratch memory)
+#define SVNET_FLUSH_POINT(p)                                                                                      \
+    do {                                                                                                          \
+        if (s_lane) ATOMIC_ADD(&d.ds_acc[(p) * Cs + lane], csum);                                                  \
+        if (v2_lane) {                                                                                            \
+            ATOMIC_ADD(&d.dv_acc[((p) * 3 + 0) * Cv + cm], cvd0);                                                  \
+            ATOMIC_ADD(&d.dv_acc[((p) * 3 + 1) * Cv + cm], cvd1);                                                  \
+            ATOMIC_ADD(&d.dv_acc[((p) * 3 + 2) * Cv + cm], cvd2);                                                  \
+        }                                                                                                         \
+        if (lane < 9) {                                                                                           \
+            float val_ = czq0;                                                                                    \
             val_ = (lane == 1) ? czq1 : val_; val_ = (lane == 2) ? czq2 : val_; val_ = (lane == 3) ? czq3 : val_; \
             val_ = (lane == 4) ? czq4 : val_; val_ = (lane == 5) ? czq5 : val_; val_ = (lane == 6) ? czq6 : val_; \
             val_ = (lane == 7) ? czq7 : val_; val_ = (lane == 8) ? czq8 : val_;                                   \
-            atomicAdd(&d.dzc[(p) * 9 + lane], val_);                                                             \
-        }                                                                                                        \
+            ATOMIC_ADD(&d.dzc[(p) * 9 + lane], val_);                                                              \
+        }                                                                                                         \
     } while (0)
 
+        EdgeIn in, nx;
+        load_edge(d, ew, E, lane, s_lane, v2_lane, diff_lane, o_lane, cm, false, in);
+#pragma unroll 1
         for (int rr = 0; rr < TE / 4; ++rr) {
             const int r = wave * (TE / 4) + rr;
-            const int64_t e = e0 + r;
-            if (e >= E) continue;
-            const int64_t gp = e / k;
-            const int64_t b = gp / d.N;
-            const int64_t jloc = d.idx[e];
-            if ((uint64_t)jloc >= (uint64_t)d.N) continue;
-            const int64_t gj = b * d.N + jloc;
+            nx.valid = false;
+            if (rr + 1 < TE / 4) load_edge(d, ew + rr + 1, E, lane, s_lane, v2_lane, diff_lane, o_lane, cm, false, nx);
+            if (!in.valid) { in = nx; continue; }
+            const int64_t gp = in.gp, gj = in.gj;
             if (gp != cur_p) {
                 if (cur_p >= 0) SVNET_FLUSH_POINT(cur_p);
                 cur_p = gp;
                 csum = 0.f;
-                cvd[0] = cvd[1] = cvd[2] = 0.f;
+                cvd0 = cvd1 = cvd2 = 0.f;
                 czq0 = czq1 = czq2 = czq3 = czq4 = czq5 = czq6 = czq7 = czq8 = 0.f;
             }
             const float* row = dxl + r * DXS;
             const float gx0 = s_lane ? row[lane] : 0.f;            // d/d(s_j - s_i) through the binarization
             const float gx1 = s_lane ? row[64 + lane] : 0.f;       // d/d(s_i)
-            dbd += gx0;
-            dbc += gx1;
-            const float gc0 = s_lane ? d.gconst[b * 2 * Cs + lane] : 0.f;        // gate path (not binarized)
-            const float gc1 = s_lane ? d.gconst[b * 2 * Cs + Cs + lane] : 0.f;
+            const float g0 = v2_lane ? row[128 + lane] : 0.f, g1 = v2_lane ? row[192 + lane] : 0.f, g2 = v2_lane ? row[256 + lane] : 0.f;
+            dbd += gx0; dbc += gx1; dbv0 += g0; dbv1 += g1; dbv2 += g2;
+            const float gc0 = s_lane ? d.gconst[in.b * 2 * Cs + lane] : 0.f;        // gate path (not binarized)
+            const float gc1 = s_lane ? d.gconst[in.b * 2 * Cs + Cs + lane] : 0.f;
             const float d0 = gx0 + gc0;
-            if (s_lane) atomicAdd(&d.ds_acc[gj * Cs + lane], d0);
             csum += (gx1 + gc1) - d0;
-
-            float gxv[3];
-#pragma unroll
-            for (int jz = 0; jz < 3; ++jz) {
-                gxv[jz] = v2_lane ? row[128 + 64 * jz + lane] : 0.f;
-                dbv[jz] += gxv[jz];
-            }
             // v2s backward: s_v[c2][jz] = sum_d ve[d][c2] * z[d][jz]
-            float ve[3], z[3][3];
-#pragma unroll
-            for (int dd = 0; dd < 3; ++dd) {
-                const float vi = v2_lane ? d.v[(gp * 3 + dd) * Cv + cm] : 0.f;
-                const float vj = diff_lane ? d.v[(gj * 3 + dd) * Cv + lane] : 0.f;
-                ve[dd] = diff_lane ? (vj - vi) : vi;
-                const float* zi = d.zz + (gp * 3 + dd) * 6;
-                const float* zj = d.zz + (gj * 3 + dd) * 6;
-#pragma unroll
-                for (int jz = 0; jz < 3; ++jz) z[dd][jz] = zj[jz] + (zi[3 + jz] - zi[jz]);
-            }
-#pragma unroll
-            for (int dd = 0; dd < 3; ++dd) {
-                const float dve = gxv[0] * z[dd][0] + gxv[1] * z[dd][1] + gxv[2] * z[dd][2];
-                if (diff_lane) {
-                    atomicAdd(&d.dv_acc[(gj * 3 + dd) * Cv + lane], dve);
-                    cvd[dd] -= dve;
-                } else if (v2_lane) {
-                    cvd[dd] += dve;
-                }
-            }
-            const float dz0 = wave_sum(gxv[0] * ve[0]), dz1 = wave_sum(gxv[1] * ve[0]), dz2 = wave_sum(gxv[2] * ve[0]);
-            const float dz3 = wave_sum(gxv[0] * ve[1]), dz4 = wave_sum(gxv[1] * ve[1]), dz5 = wave_sum(gxv[2] * ve[1]);
-            const float dz6 = wave_sum(gxv[0] * ve[2]), dz7 = wave_sum(gxv[1] * ve[2]), dz8 = wave_sum(gxv[2] * ve[2]);
+            const float ve0 = diff_lane ? (in.vj0 - in.vi0) : (v2_lane ? in.vi0 : 0.f);
+            const float ve1 = diff_lane ? (in.vj1 - in.vi1) : (v2_lane ? in.vi1 : 0.f);
+            const float ve2 = diff_lane ? (in.vj2 - in.vi2) : (v2_lane ? in.vi2 : 0.f);
+            const float dve0 = g0 * in.z0 + g1 * in.z1 + g2 * in.z2;
+            const float dve1 = g0 * in.z3 + g1 * in.z4 + g2 * in.z5;
+            const float dve2 = g0 * in.z6 + g1 * in.z7 + g2 * in.z8;
+            const float dz0 = wave_sum(g0 * ve0), dz1 = wave_sum(g1 * ve0), dz2 = wave_sum(g2 * ve0);
+            const float dz3 = wave_sum(g0 * ve1), dz4 = wave_sum(g1 * ve1), dz5 = wave_sum(g2 * ve1);
+            const float dz6 = wave_sum(g0 * ve2), dz7 = wave_sum(g1 * ve2), dz8 = wave_sum(g2 * ve2);
             czq0 += dz0; czq1 += dz1; czq2 += dz2; czq3 += dz3; czq4 += dz4; czq5 += dz5; czq6 += dz6; czq7 += dz7; czq8 += dz8;
+            if (diff_lane) { cvd0 -= dve0; cvd1 -= dve1; cvd2 -= dve2; }
+            else if (v2_lane) { cvd0 += dve0; cvd1 += dve1; cvd2 += dve2; }
+            // ---- scatter to the neighbour's rows (one contiguous segment per wave-instruction)
+            if (s_lane) ATOMIC_ADD(&d.ds_acc[gj * Cs + lane], d0);
+            if (diff_lane) {
+                ATOMIC_ADD(&d.dv_acc[(gj * 3 + 0) * Cv + lane], dve0);
+                ATOMIC_ADD(&d.dv_acc[(gj * 3 + 1) * Cv + lane], dve1);
+                ATOMIC_ADD(&d.dv_acc[(gj * 3 + 2) * Cv + lane], dve2);
+            }
             if (lane < 9) {
                 float val = dz0;
                 val = (lane == 1) ? dz1 : val; val = (lane == 2) ? dz2 : val; val = (lane == 3) ? dz3 : val;
                 val = (lane == 4) ? dz4 : val; val = (lane == 5) ? dz5 : val; val = (lane == 6) ? dz6 : val;
                 val = (lane == 7) ? dz7 : val; val = (lane == 8) ? dz8 : val;
-                atomicAdd(&d.dzp_acc[gj * 9 + lane], val);
+                ATOMIC_ADD(&d.dzp_acc[gj * 9 + lane], val);
             }
+            in = nx;
         }
         if (cur_p >= 0) SVNET_FLUSH_POINT(cur_p);
 #undef SVNET_FLUSH_POINT
         if (s_lane) {
-            atomicAdd(&d.dbeta_perm[lane], dbd);
-            atomicAdd(&d.dbeta_perm[64 + lane], dbc);
+            ATOMIC_ADD(&d.dbeta_perm[lane], dbd);
+            ATOMIC_ADD(&d.dbeta_perm[64 + lane], dbc);
         }
         if (v2_lane) {
-#pragma unroll
-            for (int jz = 0; jz < 3; ++jz) atomicAdd(&d.dbeta_perm[128 + 64 * jz + lane], dbv[jz]);
+            ATOMIC_ADD(&d.dbeta_perm[128 + lane], dbv0);
+            ATOMIC_ADD(&d.dbeta_perm[192 + lane], dbv1);
+            ATOMIC_ADD(&d.dbeta_perm[256 + lane], dbv2);
         }
     }
 }
@@ -531,8 +585,14 @@ extern "C" int svnet_edgeblock_bwd_f32(const svnet_edgeblock_bwd_desc* desc, voi
     if (E == 0) return SVNET_OK;
     const size_t lds = (size_t)TE * (d.Os + 4) * 4 + (size_t)TE * DXS * 4 + (size_t)3 * TE * NW * 8;
     const unsigned grid = (unsigned)svnet_cdiv(E, TE);
-    if (d.Os <= 64) hipLaunchKernelGGL((edgeblock_bwd_kernel<1>), dim3(grid), dim3(256), lds, (hipStream_t)stream, d);
-    else hipLaunchKernelGGL((edgeblock_bwd_kernel<2>), dim3(grid), dim3(256), lds, (hipStream_t)stream, d);
+    static const int mode = getenv("SVNET_BWD_MODE") ? atoi(getenv("SVNET_BWD_MODE")) : 0;
+#define SVNET_LAUNCH_BWD(OP, MODE) hipLaunchKernelGGL((edgeblock_bwd_kernel<OP, MODE>), dim3(grid), dim3(256), lds, (hipStream_t)stream, d)
+    if (d.Os <= 64) {
+        if (mode == 1) SVNET_LAUNCH_BWD(1, 1); else if (mode == 2) SVNET_LAUNCH_BWD(1, 2); else if (mode == 3) SVNET_LAUNCH_BWD(1, 3); else SVNET_LAUNCH_BWD(1, 0);
+    } else {
+        if (mode == 1) SVNET_LAUNCH_BWD(2, 1); else if (mode == 2) SVNET_LAUNCH_BWD(2, 2); else if (mode == 3) SVNET_LAUNCH_BWD(2, 3); else SVNET_LAUNCH_BWD(2, 0);
+    }
+#undef SVNET_LAUNCH_BWD
     SVNET_CHECK_LAUNCH("edgeblock_bwd_kernel");
     return SVNET_OK;
 }

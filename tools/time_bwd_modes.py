@@ -1,0 +1,28 @@
+"""Times edgeblock_bwd_kernel ablations (SVNET_BWD_MODE) on conv2- and conv4-shaped layers at the headline size."""
+import os, sys, subprocess, json
+if len(sys.argv) > 1:
+    import torch, contextlib, io
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from svnet_amd import _lib, config
+    from svnet_amd.models.sv_layers import SVBlock
+    from svnet_amd.models.utils.sv_util import get_graph_feature_sv, svpool
+    config.FUSE_EDGE_BLOCKS = True
+    res = {}
+    for (Cs, Cv, Os, Ov) in [(32, 10, 32, 10), (64, 21, 128, 42)]:
+        with contextlib.redirect_stdout(io.StringIO()):
+            blk = SVBlock((2 * Cs, 2 * Cv), (Os, Ov), binary=True).cuda().train()
+        s = torch.randn(32, 1024, Cs, device="cuda", requires_grad=True)
+        v = torch.randn(32, 1024, 3, Cv, device="cuda", requires_grad=True)
+        for name in ("svnet_edgeblock_bwd_f32", "svnet_edgeblock_fwd_f32"):
+            t = _lib.KernelTimer(name)
+            _lib.TIMER = t
+            for _ in range(4):
+                so, vo = svpool(blk(get_graph_feature_sv((s, v), k=20)))
+                (so.sum() + vo.sum()).backward()
+            torch.cuda.synchronize()
+            _lib.TIMER = None
+            res["%s Os=%d" % (name[16:19], Os)] = round(min(t.elapsed_ms()[1:]), 3)
+    print("MODE", os.environ.get("SVNET_BWD_MODE", "0"), json.dumps(res), flush=True)
+else:
+    for m in ("0", "1", "2", "3"):
+        subprocess.run([sys.executable, __file__, "run"], env=dict(os.environ, SVNET_BWD_MODE=m))
