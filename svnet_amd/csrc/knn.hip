@@ -157,15 +157,39 @@ __device__ __forceinline__ void wave_argmax(float& v, int& j) {
     }
 }
 
+// "a ranks before b": larger value first, equal values -> smaller index first
+__device__ __forceinline__ bool ranks_before(float va, int ja, float vb, int jb) { return (va > vb) || (va == vb && ja < jb); }
+
+// Bitonic sort of one (value, index) pair per lane across the wave; afterwards lane 0 holds the best pair, lane 63 the worst.
+__device__ __forceinline__ void wave_sort_desc(float& v, int& j, int lane) {
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (int s2 = k2 >> 1; s2 > 0; s2 >>= 1) {
+            const float ov = __shfl_xor(v, s2, 64);
+            const int oj = __shfl_xor(j, s2, 64);
+            const bool desc = (lane & k2) == 0 || k2 == 64;   // final merge: whole wave descending
+            const bool lower = (lane & s2) == 0;
+            const bool other_first = ranks_before(ov, oj, v, j);
+            // in a descending block the lower lane keeps the pair that ranks first, the upper lane the other one
+            const bool take = (lower == desc) ? other_first : !other_first;
+            v = take ? ov : v;
+            j = take ? oj : j;
+        }
+    }
+}
+
 // T candidates per lane (64*T >= N), Q query rows per wave, 4 waves per workgroup.
 template <int T, int Q>
 __global__ __launch_bounds__(256) void knn_main_kernel(const float* __restrict__ xT, const float* __restrict__ xx,
                                                        int N, int C, int k, int64_t* __restrict__ idx_out) {
+    __shared__ float cand_v[4 * 64];
+    __shared__ int cand_j[4 * 64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int b = blockIdx.y;
     const int q0 = (blockIdx.x * 4 + wave) * Q;
-    if (q0 >= N) return;  // wave-uniform
+    if (q0 >= N) return;  // wave-uniform (no workgroup barriers below: the LDS slices are per wave)
 
     const float* __restrict__ xb = xT + (size_t)b * C * N;
     const float* __restrict__ xxb = xx + (size_t)b * N;
@@ -215,21 +239,53 @@ __global__ __launch_bounds__(256) void knn_main_kernel(const float* __restrict__
             const float pd = __fsub_rn(t1, xxi);                   // fl(.. - xx[i])
             acc[q][t] = (j < N) ? pd : -INFINITY;
         }
+        // ---- top-k selection.  Threshold pass: the k-th largest of the 64 lane maxima is a lower bound of the k-th
+        // largest distance, so every winner is >= it; those few candidates (typically < 2k) are compacted into LDS
+        // with ballot prefix sums and sorted across the wave.  If more than 64 qualify (heavy ties) fall back to k
+        // rounds of wave-wide arg-max.
         int mine = 0;
-        for (int s = 0; s < k; ++s) {
-            float bv = acc[q][0];
-            int bt = 0;
+        float lm = acc[q][0];
 #pragma unroll
-            for (int t = 1; t < T; ++t) {
-                const bool g = acc[q][t] > bv;  // strict: first (lowest j) wins inside a lane
-                bv = g ? acc[q][t] : bv;
-                bt = g ? t : bt;
+        for (int t = 1; t < T; ++t) lm = fmaxf(lm, acc[q][t]);
+        {
+            float sv = lm;
+            int sj = lane;
+            wave_sort_desc(sv, sj, lane);
+            lm = __shfl(sv, k - 1, 64);   // threshold (wave-uniform)
+        }
+        int count = 0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const bool in = acc[q][t] >= lm;
+            const uint64_t m = __ballot(in);
+            const int pos = count + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (in && pos < 64) {
+                cand_v[wave * 64 + pos] = acc[q][t];
+                cand_j[wave * 64 + pos] = lane + 64 * t;
             }
-            int bj = lane + 64 * bt;
-            wave_argmax(bv, bj);
-            if (lane == s) mine = bj;
+            count += __popcll(m);
+        }
+        if (count <= 64) {  // wave-uniform
+            float cv = (lane < count) ? cand_v[wave * 64 + lane] : -INFINITY;
+            int cj = (lane < count) ? cand_j[wave * 64 + lane] : 0x7fffffff;
+            wave_sort_desc(cv, cj, lane);
+            mine = cj;
+        } else {
+            for (int s = 0; s < k; ++s) {
+                float bv = acc[q][0];
+                int bt = 0;
 #pragma unroll
-            for (int t = 0; t < T; ++t) acc[q][t] = (bj == lane + 64 * t) ? -INFINITY : acc[q][t];
+                for (int t = 1; t < T; ++t) {
+                    const bool g = acc[q][t] > bv;  // strict: first (lowest j) wins inside a lane
+                    bv = g ? acc[q][t] : bv;
+                    bt = g ? t : bt;
+                }
+                int bj = lane + 64 * bt;
+                wave_argmax(bv, bj);
+                if (lane == s) mine = bj;
+#pragma unroll
+                for (int t = 0; t < T; ++t) acc[q][t] = (bj == lane + 64 * t) ? -INFINITY : acc[q][t];
+            }
         }
         if (lane < k) idx_out[((size_t)b * N + (q0 + q)) * k + lane] = mine;
     }
