@@ -159,10 +159,13 @@ struct EdgeIn {
     float vi0, vi1, vi2, vj0, vj1, vj2;           // lane c2 < 2Cv (vj: diff lanes only)
     float z0, z1, z2, z3, z4, z5, z6, z7, z8;     // z[d*3+jz] = Zp_j - Zp_i + Zq_i
     float ui0, ui1, ui2, uj0, uj1, uj2;           // lane c' < Ov: ui = T_i - U_i, uj = U_j
+    float gv0, gv1, gv2, gt;                      // lane c' < Ov: upstream dL/dv_out, gate   (phase A)
+    float gy0, gy1; int slot0, slot1;             // lane o (+64): pooled-edge gradient and slot (phase A)
+    float gc0, gc1;                               // lane c < Cs: gate-path constants          (phase C)
 };
 
 __device__ __forceinline__ void load_edge(const svnet_edgeblock_bwd_desc& d, int64_t e, int64_t E, int lane, bool s_lane,
-                                          bool v2_lane, bool diff_lane, bool o_lane, int cm, bool want_u, EdgeIn& in) {
+                                          bool v2_lane, bool diff_lane, bool o_lane, int cm, bool want_u, bool pos0, bool pos1, EdgeIn& in) {
     const int Cs = d.Cs, Cv = d.Cv, Ov = d.Ov, k = (int)d.k;
     in.valid = e < E;
     if (!in.valid) return;
@@ -205,16 +208,31 @@ __device__ __forceinline__ void load_edge(const svnet_edgeblock_bwd_desc& d, int
         in.uj0 = uj[0 * 2 * Ov + lo];
         in.uj1 = uj[1 * 2 * Ov + lo];
         in.uj2 = uj[2 * 2 * Ov + lo];
+        // per-point operands of the edge math, fetched with the row so that nothing is loaded mid-computation
+        in.gv0 = d.gv[(gp * 3 + 0) * Ov + lo];
+        in.gv1 = d.gv[(gp * 3 + 1) * Ov + lo];
+        in.gv2 = d.gv[(gp * 3 + 2) * Ov + lo];
+        in.gt = d.gate[in.b * Ov + lo];
+        const int Os = d.Os;
+        const int o0 = min(lane, Os - 1), o1 = min(lane + 64, Os - 1);
+        in.gy0 = d.gy[gp * Os + o0];
+        in.gy1 = d.gy[gp * Os + o1];
+        in.slot0 = pos0 ? d.slot_max[gp * Os + o0] : d.slot_min[gp * Os + o0];
+        in.slot1 = pos1 ? d.slot_max[gp * Os + o1] : d.slot_min[gp * Os + o1];
+    } else {
+        in.gc0 = d.gconst[in.b * 2 * Cs + ls];
+        in.gc1 = d.gconst[in.b * 2 * Cs + Cs + ls];
     }
 }
 
 template <int OP, int MODE>  // MODE: 0 = product; 1..3 = timing-only ablations (SVNET_BWD_MODE), wrong results
-__global__ __launch_bounds__(256) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_desc d) {
+__global__ __launch_bounds__(256, (OP == 1 ? 3 : 2)) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_desc d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Cs = d.Cs, Cv = d.Cv, Os = d.Os, Ov = d.Ov;
     const int DNS = Os + 4;
-    float* dnl = reinterpret_cast<float*>(smem);                    // [TE][DNS]   dL/dn = dy_pre*scale
-    float* dxl = dnl + TE * DNS;                                     // [TE][DXS]   masked dx_b
+    float* dxl = reinterpret_cast<float*>(smem);                    // [TE][DXS]   masked dx_b            (phases B -> C)
+    float* dnl = dxl;                                                // [TE][DNS]   dL/dn = dy_pre*scale   (phases A -> B), ALIASES dxl:
+                                                                     //             phase B pulls it into registers before writing dxl
     uint64_t* pl = reinterpret_cast<uint64_t*>(dxl + TE * DXS);      // [3][TE][NW] sign | nz | ste (row-major words)
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -264,14 +282,14 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_
         int64_t cur_p = -1;
         float cv0 = 0.f, cv1 = 0.f, cv2 = 0.f;   // centre sum of dv' for the current point
         EdgeIn in, nx;
-        load_edge(d, ew, E, lane, s_lane, v2_lane, diff_lane, o_lane, cm, true, in);
+        load_edge(d, ew, E, lane, s_lane, v2_lane, diff_lane, o_lane, cm, true, a1[0] >= 0.f, a1[OP - 1] >= 0.f, in);
 #pragma unroll 1
         for (int rr = 0; rr < TE / 4; ++rr) {
             const int r = wave * (TE / 4) + rr;
             // issue the NEXT edge's loads before this edge's atomics: vmcnt retires in order, so loads queued behind
             // atomics would expose the full atomic latency on every edge
             nx.valid = false;
-            if (rr + 1 < TE / 4) load_edge(d, ew + rr + 1, E, lane, s_lane, v2_lane, diff_lane, o_lane, cm, true, nx);
+            if (rr + 1 < TE / 4) load_edge(d, ew + rr + 1, E, lane, s_lane, v2_lane, diff_lane, o_lane, cm, true, a1[0] >= 0.f, a1[OP - 1] >= 0.f, nx);
             if (!in.valid) {  // wave-uniform: rows past the end (or corrupted ids) contribute zeros
                 for (int o = lane; o < Os; o += 64) dnl[r * DNS + o] = 0.f;
                 if (lane < NW) { pl[(0 * TE + r) * NW + lane] = 0ull; pl[(1 * TE + r) * NW + lane] = 0ull; pl[(2 * TE + r) * NW + lane] = 0ull; }
@@ -321,8 +339,8 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_
                     int n = 0;
 #pragma unroll
                     for (int w = 0; w < NW; ++w) n += tdot(xs[w], xz[w], wsg[op][w], wnz[op][w]);
-                    const int slot = (a1[op] >= 0.f) ? d.slot_max[gp * Os + o] : d.slot_min[gp * Os + o];
-                    const float g = (slot == in.t) ? d.gy[gp * Os + o] : 0.f;
+                    const int slot = op == 0 ? in.slot0 : in.slot1;
+                    const float g = (slot == in.t) ? (op == 0 ? in.gy0 : in.gy1) : 0.f;
                     const float xh = (sc1[op] * (float)n - my[op]) * iy[op];
                     const float dyp = cs[op] * (g - m1[op] - xh * m2[op]);
                     d.dn_out[e * Os + o] = dyp;
@@ -331,10 +349,9 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_
             }
             // ---- vector path: v' = U_j - U_i + T_i, out = gate * mean_k v'*(Av + Bv/n')
             if (o_lane) {
-                const float gt = d.gate[in.b * Ov + lane] * invk;
+                const float gt = in.gt * invk;
                 const float vp0 = in.uj0 + in.ui0, vp1 = in.uj1 + in.ui1, vp2 = in.uj2 + in.ui2;
-                const float ge0 = d.gv[(gp * 3 + 0) * Ov + lane] * gt, ge1 = d.gv[(gp * 3 + 1) * Ov + lane] * gt,
-                            ge2 = d.gv[(gp * 3 + 2) * Ov + lane] * gt;
+                const float ge0 = in.gv0 * gt, ge1 = in.gv1 * gt, ge2 = in.gv2 * gt;
                 const float nv = sqrtf(vp0 * vp0 + vp1 * vp1 + vp2 * vp2);
                 const float nn = nv + VEPS;
                 const float q = avc + bvc / nn;
@@ -404,11 +421,10 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             if (ks < nks) {
-                float x[8];
                 const int kk = ks * 16 + 8 * h;
                 const float4 x0 = *reinterpret_cast<const float4*>(&dnl[r * DNS + kk]);      // DNS % 4 == 0, kk % 8 == 0
                 const float4 x1 = *reinterpret_cast<const float4*>(&dnl[r * DNS + kk + 4]);  // Os % 8 == 0: no ragged k
-                x[0] = x0.x; x[1] = x0.y; x[2] = x0.z; x[3] = x0.w; x[4] = x1.x; x[5] = x1.y; x[6] = x1.z; x[7] = x1.w;
+                const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
                 bf16x8 fh, fm, fl;
                 split3_frag(x, fh, fm, fl);
 #pragma unroll
@@ -421,6 +437,7 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_
                 }
             }
         }
+        __syncthreads();   // every wave has consumed dnl: dxl may now overwrite the same LDS bytes
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int ct = wave + 4 * q;
@@ -465,12 +482,12 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_
     } while (0)
 
         EdgeIn in, nx;
-        load_edge(d, ew, E, lane, s_lane, v2_lane, diff_lane, o_lane, cm, false, in);
+        load_edge(d, ew, E, lane, s_lane, v2_lane, diff_lane, o_lane, cm, false, false, false, in);
 #pragma unroll 1
         for (int rr = 0; rr < TE / 4; ++rr) {
             const int r = wave * (TE / 4) + rr;
             nx.valid = false;
-            if (rr + 1 < TE / 4) load_edge(d, ew + rr + 1, E, lane, s_lane, v2_lane, diff_lane, o_lane, cm, false, nx);
+            if (rr + 1 < TE / 4) load_edge(d, ew + rr + 1, E, lane, s_lane, v2_lane, diff_lane, o_lane, cm, false, false, false, nx);
             if (!in.valid) { in = nx; continue; }
             const int64_t gp = in.gp, gj = in.gj;
             if (gp != cur_p) {
@@ -485,8 +502,7 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_
             const float gx1 = s_lane ? row[64 + lane] : 0.f;       // d/d(s_i)
             const float g0 = v2_lane ? row[128 + lane] : 0.f, g1 = v2_lane ? row[192 + lane] : 0.f, g2 = v2_lane ? row[256 + lane] : 0.f;
             dbd += gx0; dbc += gx1; dbv0 += g0; dbv1 += g1; dbv2 += g2;
-            const float gc0 = s_lane ? d.gconst[in.b * 2 * Cs + lane] : 0.f;        // gate path (not binarized)
-            const float gc1 = s_lane ? d.gconst[in.b * 2 * Cs + Cs + lane] : 0.f;
+            const float gc0 = s_lane ? in.gc0 : 0.f, gc1 = s_lane ? in.gc1 : 0.f;   // gate path (not binarized)
             const float d0 = gx0 + gc0;
             csum += (gx1 + gc1) - d0;
             // v2s backward: s_v[c2][jz] = sum_d ve[d][c2] * z[d][jz]
@@ -583,7 +599,7 @@ extern "C" int svnet_edgeblock_bwd_f32(const svnet_edgeblock_bwd_desc* desc, voi
                       d.Ov <= 64, SVNET_E_UNSUPPORTED, "svnet_edgeblock_bwd_f32: channel counts outside Cs<=64, 2Cv<=64, Os<=128 (mult of 8), Ov<=64");
     const int64_t E = d.B * d.N * d.k;
     if (E == 0) return SVNET_OK;
-    const size_t lds = (size_t)TE * (d.Os + 4) * 4 + (size_t)TE * DXS * 4 + (size_t)3 * TE * NW * 8;
+    const size_t lds = (size_t)TE * DXS * 4 + (size_t)3 * TE * NW * 8;   // dnl aliases dxl
     const unsigned grid = (unsigned)svnet_cdiv(E, TE);
     static const int mode = getenv("SVNET_BWD_MODE") ? atoi(getenv("SVNET_BWD_MODE")) : 0;
 #define SVNET_LAUNCH_BWD(OP, MODE) hipLaunchKernelGGL((edgeblock_bwd_kernel<OP, MODE>), dim3(grid), dim3(256), lds, (hipStream_t)stream, d)

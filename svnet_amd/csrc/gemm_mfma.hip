@@ -180,20 +180,25 @@ struct TnArgs {
     const uint64_t* b_sign; const uint64_t* b_nz;   // BMODE 1: row-sliced planes [ceil(M/64)][Q]
     float* C; int64_t c_ps, c_qs;       // out(p,q) at C[p*c_ps + q*c_qs], accumulated with atomics (pre-zeroed)
     int64_t M; int P, Q;
-    int64_t rows_per_block;             // multiple of 64
+    int64_t rows_per_block;             // multiple of 256
+    int ptiles_per_block;               // p tiles (32 wide) handled by the 4 waves of a workgroup: 1, 2 or 4
     float alpha;
 };
 
-// NQ 32-wide q tiles per workgroup (blockIdx.z picks the group); wave w owns p tile blockIdx.y*4 + w.
+// NQ 32-wide q tiles per workgroup (blockIdx.z picks the group).  The 4 waves cover `ptw` p tiles (1, 2 or 4 per
+// workgroup); when P is narrow (ptw < 4) the spare waves split the workgroup's row range instead of idling.
 template <int NQ, int BMODE>
 __global__ __launch_bounds__(256) void mfma_tn_kernel(TnArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int p0 = (blockIdx.y * 4 + wave) * 32;
+    const int ptw = a.ptiles_per_block;                      // 1, 2 or 4
+    const int p0 = (blockIdx.y * ptw + (wave % ptw)) * 32;
     const int q0 = blockIdx.z * (NQ * 32);
     if (p0 >= a.P) return;  // wave-uniform; no barriers in this kernel
-    const int64_t mb = (int64_t)blockIdx.x * a.rows_per_block;
-    const int64_t me = min(a.M, mb + a.rows_per_block);
+    const int nsub = 4 / ptw, sub = wave / ptw;
+    const int64_t rows_sub = ((a.rows_per_block / nsub + 63) >> 6) << 6;   // multiple of 64
+    const int64_t mb = (int64_t)blockIdx.x * a.rows_per_block + (int64_t)sub * rows_sub;
+    const int64_t me = min(min(a.M, (int64_t)(blockIdx.x + 1) * a.rows_per_block), mb + rows_sub);
     const int p = p0 + r;
     const bool p_ok = p < a.P;
 
@@ -290,9 +295,11 @@ void launch_rows(const RowsArgs& a, hipStream_t st) {
 
 template <int NQ, int BMODE>
 void launch_tn(TnArgs a, hipStream_t st) {
-    const int gy = (int)svnet_cdiv(a.P, 128), gz = (int)svnet_cdiv(a.Q, NQ * 32);
+    const int ptiles = (int)svnet_cdiv(a.P, 32);
+    a.ptiles_per_block = ptiles >= 3 ? 4 : ptiles;
+    const int gy = (int)svnet_cdiv(ptiles, a.ptiles_per_block), gz = (int)svnet_cdiv(a.Q, NQ * 32);
     int64_t want = svnet_cdiv(1024, (int64_t)gy * gz);               // ~4 workgroups per CU in total
-    int64_t rpb = svnet_cdiv(svnet_cdiv(a.M, want), 64) * 64;
+    int64_t rpb = svnet_cdiv(svnet_cdiv(a.M, want), 256) * 256;
     if (rpb < 256) rpb = 256;
     a.rows_per_block = rpb;
     const int64_t gx = svnet_cdiv(a.M, rpb);
@@ -335,6 +342,7 @@ int svnet_mfma_tn(const float* A, int64_t lda, const float* B, int64_t ldb, cons
     if (Q <= 32) { if (tern) launch_tn<1, 1>(a, st); else launch_tn<1, 0>(a, st); }
     else if (Q <= 64) { if (tern) launch_tn<2, 1>(a, st); else launch_tn<2, 0>(a, st); }
     else if (Q <= 128) { if (tern) launch_tn<4, 1>(a, st); else launch_tn<4, 0>(a, st); }
+    else if (Q <= 160 || Q == 320) { if (tern) launch_tn<5, 1>(a, st); else launch_tn<5, 0>(a, st); }   // 320 = fused edge block
     else { if (tern) launch_tn<8, 1>(a, st); else launch_tn<8, 0>(a, st); }
     SVNET_CHECK_LAUNCH("mfma_tn_kernel");
     return SVNET_OK;
