@@ -186,6 +186,47 @@ int svnet_edgeblock_bwd_coeffs_f32(const float* red, const float* redv, const fl
                                    float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, void* stream);
 int svnet_edgeblock_bwd_f32(const svnet_edgeblock_bwd_desc* desc, void* stream);
 
+/* ------------------------------------------------------------------ fused FIRST edge layer (full precision)
+ * get_graph_feature (sv_util.py:28-62) -> Vector2Scalar(2,3) (init_scalar, sv_layers.py:111-129)
+ * -> SVBlock((6,2),(Os,Ov)) fp (sv_layers.py:172-196) -> svpool (sv_util.py:118-132) in one pass over the edges
+ * (csrc/xyzblock.hip).  x: contiguous [B,3,N]; idx [B*N,k] cloud-local; w0/wz: [3,2] (init_scalar / block v2s),
+ * w1: [Os,12], w2: [Ov,2].  Per-point outputs as for the binarized block, with fp32 y_max / y_min instead of
+ * integer sums; stat_y [2*Os], stat_v [2*Ov] fp64 sums and gate_sum [B,6] accumulate (caller zero-fills).       */
+typedef struct svnet_xyzblock_desc {
+    int64_t B, N, k;
+    int Os, Ov;
+    const float* x; const int64_t* idx;
+    const float* w0; const float* wz; const float* w1; const float* w2;
+    float* y_max; float* y_min; uint8_t* slot_max; uint8_t* slot_min;
+    float* mv; float* mvn;
+    double* stat_y; double* stat_v; float* gate_sum;
+} svnet_xyzblock_desc;
+int svnet_xyzblock_fwd_f32(const svnet_xyzblock_desc* desc, void* stream);
+/* coef: same layout as svnet_edgeblock_coeffs_f32 (A1 = gamma*invstd, B1 = beta - gamma*mean*invstd, ...).        */
+int svnet_xyzblock_coeffs_f32(const double* stat_y, const double* stat_v, int64_t E, int64_t Os, int64_t Ov,
+                              const float* gamma1, const float* beta1, float* running_mean1, float* running_var1,
+                              const float* gamma2, const float* beta2, float* running_mean2, float* running_var2,
+                              int training, float eps, float momentum, float* coef, void* stream);
+int svnet_xyzblock_apply_f32(const float* y_max, const float* y_min, const float* mv, const float* mvn, const float* coef,
+                             const float* gate, int64_t P, int64_t N, int64_t Os, int64_t Ov, float slope, float* s_out,
+                             float* v_out, void* stream);
+/* Backward: the coordinates need no gradient, so the edge pass only accumulates parameter gradients
+ * gw = [dW1 (Os*12) | dW2 (Ov*2) | dW0 (6) | dWz (6)] (float atomics, caller zero-fills).  bcoef comes from
+ * svnet_edgeblock_bwd_coeffs_f32 (same coefficient layout); gconst [B,6] = dL/d(gate input) / (N*k).             */
+int svnet_xyzblock_bwd_prelude_f32(const float* gs, const float* gv, const float* y_max, const float* y_min, const float* mv,
+                                   const float* mvn, const float* coef, const float* gate, int64_t P, int64_t N, int64_t Os,
+                                   int64_t Ov, float slope, float* gy, float* red, float* redv, float* dgate, void* stream);
+typedef struct svnet_xyzblock_bwd_desc {
+    int64_t B, N, k;
+    int Os, Ov;
+    const float* x; const int64_t* idx;
+    const float* w0; const float* wz; const float* w1; const float* w2;
+    const uint8_t* slot_max; const uint8_t* slot_min;
+    const float* coef; const float* bcoef; const float* gate; const float* gy; const float* gv; const float* gconst;
+    float* gw;
+} svnet_xyzblock_bwd_desc;
+int svnet_xyzblock_bwd_f32(const svnet_xyzblock_bwd_desc* desc, void* stream);
+
 /* ------------------------------------------------------------------ Vector2Scalar (sv_layers.py:104-129)
  * v: [M,3,C]; w_eff: [J,C] effective weights (scale*sign(W) or W); z[m,i,j] = sum_c v[m,i,c] w_eff[j,c];
  * s[m, d*J+j] = sum_i v[m,i,d] z[m,i,j].  z_out optional ([M,3,J]).  J <= 4, C <= 192.              */

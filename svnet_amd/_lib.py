@@ -69,6 +69,32 @@ class EdgeBlockBwdDesc(ctypes.Structure):
     ]
 
 
+class XyzBlockDesc(ctypes.Structure):
+    """struct svnet_xyzblock_desc (include/svnet_hip.h)."""
+    _fields_ = [
+        ("B", c_i64), ("N", c_i64), ("k", c_i64),
+        ("Os", c_int), ("Ov", c_int),
+        ("x", c_p), ("idx", c_p),
+        ("w0", c_p), ("wz", c_p), ("w1", c_p), ("w2", c_p),
+        ("y_max", c_p), ("y_min", c_p), ("slot_max", c_p), ("slot_min", c_p),
+        ("mv", c_p), ("mvn", c_p),
+        ("stat_y", c_p), ("stat_v", c_p), ("gate_sum", c_p),
+    ]
+
+
+class XyzBlockBwdDesc(ctypes.Structure):
+    """struct svnet_xyzblock_bwd_desc (include/svnet_hip.h)."""
+    _fields_ = [
+        ("B", c_i64), ("N", c_i64), ("k", c_i64),
+        ("Os", c_int), ("Ov", c_int),
+        ("x", c_p), ("idx", c_p),
+        ("w0", c_p), ("wz", c_p), ("w1", c_p), ("w2", c_p),
+        ("slot_max", c_p), ("slot_min", c_p),
+        ("coef", c_p), ("bcoef", c_p), ("gate", c_p), ("gy", c_p), ("gv", c_p), ("gconst", c_p),
+        ("gw", c_p),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/svnet_hip.h declares
 SIGNATURES = {
     "svnet_version": (c_int, []),
@@ -90,6 +116,11 @@ SIGNATURES = {
     "svnet_edgeblock_bwd_prelude_f32": (c_int, [c_p] * 9 + [c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p, c_p, c_p]),
     "svnet_edgeblock_bwd_coeffs_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_p]),
     "svnet_edgeblock_bwd_f32": (c_int, [ctypes.POINTER(EdgeBlockBwdDesc), c_p]),
+    "svnet_xyzblock_fwd_f32": (c_int, [ctypes.POINTER(XyzBlockDesc), c_p]),
+    "svnet_xyzblock_coeffs_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_f, c_f, c_p, c_p]),
+    "svnet_xyzblock_apply_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p]),
+    "svnet_xyzblock_bwd_prelude_f32": (c_int, [c_p] * 8 + [c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p, c_p, c_p]),
+    "svnet_xyzblock_bwd_f32": (c_int, [ctypes.POINTER(XyzBlockBwdDesc), c_p]),
     "svnet_v2s_fwd_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "svnet_v2s_bwd_f32": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "svnet_colstats_f64": (c_int, [c_p, c_i64, c_i64, c_int, c_p, c_p]),

@@ -667,6 +667,107 @@ class EdgeBlock(torch.autograd.Function):
                 dsc1.view_as(scale1), dg1, db1, None, None, dW2, dsc2.view_as(sc2), dg2, db2, None, None, dWg0, dWg2)
 
 
+class XyzBlock(torch.autograd.Function):
+    """get_graph_feature -> init_scalar (Vector2Scalar) -> SVBlock (fp) -> svpool(max, mean) of the FIRST edge layer in one
+    pass over the edges (csrc/xyzblock.hip).  The coordinates receive no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, idx, k, training, W0, Wz, W1, g1, b1, rm1, rv1, W2, g2, b2, rm2, rv2, Wg0, Wg2):
+        _hip(x, idx)
+        from ._lib import XyzBlockDesc
+        x = _f32c(x.detach())
+        B, _, N = x.shape
+        Os, Ov = W1.shape[0], W2.shape[0]
+        P, E = B * N, B * N * k
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        idx = idx.contiguous()
+        y_max, y_min = torch.empty((P, Os), **f32), torch.empty((P, Os), **f32)
+        slot_max = torch.empty((P, Os), dtype=torch.uint8, device=dev)
+        slot_min = torch.empty((P, Os), dtype=torch.uint8, device=dev)
+        mv, mvn = torch.empty((P, 3, Ov), **f32), torch.empty((P, 3, Ov), **f32)
+        stat_y = torch.zeros((2 * Os,), dtype=torch.float64, device=dev) if training else None
+        stat_v = torch.zeros((2 * Ov,), dtype=torch.float64, device=dev) if training else None
+        gate_sum = torch.zeros((B, 6), **f32)
+        W0c, Wzc, W1c, W2c = _f32c(W0), _f32c(Wz), _f32c(W1), _f32c(W2)
+        d = XyzBlockDesc()
+        d.B, d.N, d.k, d.Os, d.Ov = B, N, k, Os, Ov
+        d.x, d.idx, d.w0, d.wz, d.w1, d.w2 = _p(x), _p(idx), _p(W0c), _p(Wzc), _p(W1c), _p(W2c)
+        d.y_max, d.y_min, d.slot_max, d.slot_min, d.mv, d.mvn = _p(y_max), _p(y_min), _p(slot_max), _p(slot_min), _p(mv), _p(mvn)
+        d.stat_y, d.stat_v, d.gate_sum = _p(stat_y), _p(stat_v), _p(gate_sum)
+        call("svnet_xyzblock_fwd_f32", ctypes.byref(d), _stream())
+
+        gin = gate_sum * (1.0 / float(N * k))
+        H = Wg0.shape[0]
+        hpre = torch.empty((B, H), **f32)
+        gemm(B, H, 6, A=gin, a_rs=6, a_cs=1, B=_f32c(Wg0), b_rs=1, b_cs=6, C=hpre, ldc=H)
+        h = _act_raw(hpre, 1)
+        gpre = torch.empty((B, Ov), **f32)
+        gemm(B, Ov, H, A=h, a_rs=H, a_cs=1, B=_f32c(Wg2), b_rs=1, b_cs=H, C=gpre, ldc=Ov)
+        gate = _act_raw(gpre, 2)
+
+        coef = torch.empty((4 * Os + 4 * Ov,), **f32)
+        call("svnet_xyzblock_coeffs_f32", _p(stat_y), _p(stat_v), E, Os, Ov, _p(g1), _p(b1), _p(rm1), _p(rv1), _p(g2), _p(b2), _p(rm2),
+             _p(rv2), int(training), BN_EPS, BN_MOMENTUM, _p(coef), _stream())
+        s_out = torch.empty((B, N, Os), **f32)
+        v_out = torch.empty((B, N, 3, Ov), **f32)
+        call("svnet_xyzblock_apply_f32", _p(y_max), _p(y_min), _p(mv), _p(mvn), _p(coef), _p(gate), P, N, Os, Ov, 0.2, _p(s_out), _p(v_out),
+             _stream())
+        ctx.save_for_backward(x, idx, W0c, Wzc, W1c, W2c, y_max, y_min, slot_max, slot_min, mv, mvn, coef, gate, h, gin, g1, g2, Wg0, Wg2)
+        ctx.meta = (B, N, k, Os, Ov, bool(training))
+        return s_out, v_out
+
+    @staticmethod
+    def backward(ctx, gs, gv):
+        from ._lib import XyzBlockBwdDesc
+        (x, idx, W0, Wz, W1, W2, y_max, y_min, slot_max, slot_min, mv, mvn, coef, gate, h, gin, g1, g2, Wg0, Wg2) = ctx.saved_tensors
+        B, N, k, Os, Ov, training = ctx.meta
+        P, E = B * N, B * N * k
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        gs = _f32c(gs).reshape(P, Os)
+        gv = _f32c(gv).reshape(P, 3, Ov)
+        gy = torch.empty((P, Os), **f32)
+        red, redv = torch.zeros((2 * Os,), **f32), torch.zeros((2 * Ov,), **f32)
+        dgate = torch.zeros((B, Ov), **f32)
+        call("svnet_xyzblock_bwd_prelude_f32", _p(gs), _p(gv), _p(y_max), _p(y_min), _p(mv), _p(mvn), _p(coef), _p(gate), P, N, Os, Ov, 0.2,
+             _p(gy), _p(red), _p(redv), _p(dgate), _stream())
+        bcoef = torch.empty((3 * Os + 2 * Ov,), **f32)
+        dg1, db1 = torch.empty((Os,), **f32), torch.empty((Os,), **f32)
+        dg2, db2 = torch.empty((Ov,), **f32), torch.empty((Ov,), **f32)
+        call("svnet_edgeblock_bwd_coeffs_f32", _p(red), _p(redv), _p(coef), _p(g1), _p(g2), E, Os, Ov, int(training), _p(bcoef), _p(dg1),
+             _p(db1), _p(dg2), _p(db2), _stream())
+        # gate MLP backward
+        H = Wg0.shape[0]
+        dgpre = torch.empty_like(dgate)
+        call("svnet_act_bwd_f32", _p(dgate), _p(gate), dgate.numel(), 2, _p(dgpre), _stream())
+        dWg2 = torch.empty((Ov, H), **f32)
+        gemm(Ov, H, B, A=dgpre, a_rs=1, a_cs=Ov, B=h, b_rs=H, b_cs=1, C=dWg2, ldc=H)
+        dh = torch.empty((B, H), **f32)
+        gemm(B, H, Ov, A=dgpre, a_rs=Ov, a_cs=1, B=_f32c(Wg2), b_rs=H, b_cs=1, C=dh, ldc=H)
+        dhpre = torch.empty_like(dh)
+        call("svnet_act_bwd_f32", _p(dh), _p(h), dh.numel(), 1, _p(dhpre), _stream())
+        dWg0 = torch.empty((H, 6), **f32)
+        gemm(H, 6, B, A=dhpre, a_rs=1, a_cs=H, B=gin, b_rs=6, b_cs=1, C=dWg0, ldc=6)
+        gconst = torch.empty((B, 6), **f32)
+        gemm(B, 6, H, A=dhpre, a_rs=H, a_cs=1, B=_f32c(Wg0), b_rs=6, b_cs=1, C=gconst, ldc=6, alpha=1.0 / float(N * k))
+        # edge pass: parameter gradients
+        gw = torch.zeros((Os * 12 + Ov * 2 + 12,), **f32)
+        d = XyzBlockBwdDesc()
+        d.B, d.N, d.k, d.Os, d.Ov = B, N, k, Os, Ov
+        d.x, d.idx, d.w0, d.wz, d.w1, d.w2 = _p(x), _p(idx), _p(W0), _p(Wz), _p(W1), _p(W2)
+        d.slot_max, d.slot_min, d.coef, d.bcoef, d.gate = _p(slot_max), _p(slot_min), _p(coef), _p(bcoef), _p(gate)
+        d.gy, d.gv, d.gconst, d.gw = _p(gy), _p(gv), _p(gconst), _p(gw)
+        call("svnet_xyzblock_bwd_f32", ctypes.byref(d), _stream())
+        o = Os * 12
+        dW1 = gw[:o].view(Os, 12)
+        dW2 = gw[o:o + Ov * 2].view(Ov, 2)
+        dW0 = gw[o + Ov * 2:o + Ov * 2 + 6].view(3, 2)
+        dWz = gw[o + Ov * 2 + 6:].view(3, 2)
+        # forward args: x, idx, k, training, W0, Wz, W1, g1, b1, rm1, rv1, W2, g2, b2, rm2, rv2, Wg0, Wg2
+        return (None, None, None, None, dW0, dWz, dW1, dg1, db1, None, None, dW2, dg2, db2, None, None, dWg0, dWg2)
+
+
 _PERM_CACHE = {}
 DEBUG_BUFFER = None     # optional int64[4] device tensor: first out-of-range neighbour id seen by the fused backward
 

@@ -1,0 +1,456 @@
+// Fused FIRST edge layer (full precision): xyz k-NN gather -> Vector2Scalar -> SVBlock(fp) -> neighbour pooling in one
+// pass over the edges, forward and backward, without materialising an edge tensor.
+//
+// Replaces, for the first layer of the DGCNN models (sv_dgcnn_cls.py:49-53, sv_dgcnn_partseg.py:85-89), the chain
+//   get_graph_feature (sv_util.py:28-62) -> init_scalar = Vector2Scalar(2,3) (sv_layers.py:111-129)
+//   -> conv1 = SVBlock((6,2),(Os,Ov)) (sv_layers.py:172-196, never binarized) -> svpool (sv_util.py:118-132).
+// An edge row is a function of six floats (x_i, x_j): v_e = [x_j - x_i, x_i] (3x2), s = v2s(v_e; W0) (6),
+// s_v = v2s(v_e; Wz) (6), y = W1 [s, s_v] (Os), v' = v_e W2^T (3 x Ov).  One wave per point, lanes are output
+// channels; the 12 input features are wave-uniform.  As in edgeblock.hip, max_k commutes with the monotone
+// BatchNorm+LeakyReLU (keep max_k y, min_k y and their slots) and VectorBN is affine in (v', v'/|v'|).
+// The input coordinates need no gradient, so the backward is a pure reduction into the (tiny) parameter gradients:
+// per-lane register accumulators, flushed once per wave with float atomics.
+#include <float.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr float VEPS = 1e-6f;
+
+struct XyzFwdArgs {
+    svnet_xyzblock_desc d;
+    int waves_per_cloud, points_per_wave;
+};
+
+// v_e and the 12 scalar features of one edge (all wave-uniform values, computed redundantly by every lane)
+struct EdgeFeat {
+    float ve[3][2];
+    float f[12];      // [s (c2*3+jz) | s_v (c2*3+jz)]
+};
+
+__device__ __forceinline__ void edge_features(const float xi[3], const float xj[3], const float (&w0)[3][2], const float (&wz)[3][2],
+                                              EdgeFeat& e) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        e.ve[d][0] = xj[d] - xi[d];
+        e.ve[d][1] = xi[d];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float (&w)[3][2] = h == 0 ? w0 : wz;
+        float z[3][3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int jz = 0; jz < 3; ++jz) z[d][jz] = e.ve[d][0] * w[jz][0] + e.ve[d][1] * w[jz][1];
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int jz = 0; jz < 3; ++jz)
+                e.f[h * 6 + c2 * 3 + jz] = e.ve[0][c2] * z[0][jz] + e.ve[1][c2] * z[1][jz] + e.ve[2][c2] * z[2][jz];
+    }
+}
+
+__device__ __forceinline__ void load_small(const float* __restrict__ p, float (&w)[3][2]) {
+#pragma unroll
+    for (int jz = 0; jz < 3; ++jz) { w[jz][0] = p[jz * 2 + 0]; w[jz][1] = p[jz * 2 + 1]; }
+}
+
+__global__ __launch_bounds__(256) void xyzblock_fwd_kernel(XyzFwdArgs fa) {
+    const svnet_xyzblock_desc& d = fa.d;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_g = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t b = wave_g / fa.waves_per_cloud;
+    if (b >= d.B) return;  // wave-uniform
+    const int wi = (int)(wave_g - b * fa.waves_per_cloud);
+    const int p_begin = wi * fa.points_per_wave;
+    const int p_end = min((int)d.N, p_begin + fa.points_per_wave);
+    const int Os = d.Os, Ov = d.Ov, k = (int)d.k;
+    const int64_t N = d.N;
+    const float* xb = d.x + b * 3 * N;
+
+    float w0[3][2], wz[3][2];
+    load_small(d.w0, w0);
+    load_small(d.wz, wz);
+    const bool o_lane = lane < Os, v_lane = lane < Ov;
+    float w1[12];
+#pragma unroll
+    for (int f = 0; f < 12; ++f) w1[f] = o_lane ? d.w1[lane * 12 + f] : 0.f;
+    const float w2a = v_lane ? d.w2[lane * 2 + 0] : 0.f, w2b = v_lane ? d.w2[lane * 2 + 1] : 0.f;
+
+    double sy1 = 0.0, sy2 = 0.0, sv1 = 0.0, sv2 = 0.0;
+    float gsum[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    for (int p = p_begin; p < p_end; ++p) {
+        const int64_t gp = b * N + p;
+        const float xi[3] = {xb[p], xb[N + p], xb[2 * N + p]};
+        float ymax = -FLT_MAX, ymin = FLT_MAX;
+        int smax = 0, smin = 0;
+        float av[3] = {0.f, 0.f, 0.f}, avn[3] = {0.f, 0.f, 0.f};
+        for (int t = 0; t < k; ++t) {
+            const int64_t j = d.idx[gp * k + t];
+            const float xj[3] = {xb[j], xb[N + j], xb[2 * N + j]};
+            EdgeFeat e;
+            edge_features(xi, xj, w0, wz, e);
+#pragma unroll
+            for (int f = 0; f < 6; ++f) gsum[f] += e.f[f];
+            float y = 0.f;
+#pragma unroll
+            for (int f = 0; f < 12; ++f) y = fmaf(w1[f], e.f[f], y);
+            if (y > ymax) { ymax = y; smax = t; }
+            if (y < ymin) { ymin = y; smin = t; }
+            sy1 += (double)y;
+            sy2 += (double)y * (double)y;
+            float vp[3];
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd) vp[dd] = w2a * e.ve[dd][0] + w2b * e.ve[dd][1];
+            const float nn = sqrtf(vp[0] * vp[0] + vp[1] * vp[1] + vp[2] * vp[2]) + VEPS;
+            const float inv = 1.f / nn;
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd) { av[dd] += vp[dd]; avn[dd] += vp[dd] * inv; }
+            sv1 += (double)nn;
+            sv2 += (double)nn * (double)nn;
+        }
+        const float invk = 1.f / (float)k;
+        if (o_lane) {
+            d.y_max[gp * Os + lane] = ymax;
+            d.y_min[gp * Os + lane] = ymin;
+            d.slot_max[gp * Os + lane] = (uint8_t)smax;
+            d.slot_min[gp * Os + lane] = (uint8_t)smin;
+        }
+        if (v_lane) {
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd) {
+                d.mv[(gp * 3 + dd) * Ov + lane] = av[dd] * invk;
+                d.mvn[(gp * 3 + dd) * Ov + lane] = avn[dd] * invk;
+            }
+        }
+    }
+    if (p_begin < p_end) {
+        if (d.stat_y) {
+            if (o_lane) { atomicAdd(&d.stat_y[lane], sy1); atomicAdd(&d.stat_y[Os + lane], sy2); }
+            if (v_lane) { atomicAdd(&d.stat_v[lane], sv1); atomicAdd(&d.stat_v[Ov + lane], sv2); }
+        }
+        if (lane < 6) {
+            float val = gsum[0];
+#pragma unroll
+            for (int f = 1; f < 6; ++f) val = (lane == f) ? gsum[f] : val;
+            atomicAdd(&d.gate_sum[b * 6 + lane], val);
+        }
+    }
+}
+
+// coef = [A1 | B1 | mean_y | invstd_y (Os each) | Av | Bv | mean_n' | invstd_n' (Ov each)]  (same layout as edgeblock)
+__global__ void xyzblock_coeffs_kernel(const double* __restrict__ stat_y, const double* __restrict__ stat_v, int64_t E, int Os, int Ov,
+                                       const float* __restrict__ g1, const float* __restrict__ b1, float* __restrict__ rm1,
+                                       float* __restrict__ rv1, const float* __restrict__ g2, const float* __restrict__ b2,
+                                       float* __restrict__ rm2, float* __restrict__ rv2, int training, float eps, float momentum,
+                                       float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int part = 0; part < 2; ++part) {
+        const int C = part == 0 ? Os : Ov;
+        if (c >= C) continue;
+        const double* st = part == 0 ? stat_y : stat_v;
+        const float* g = part == 0 ? g1 : g2;
+        const float* bb = part == 0 ? b1 : b2;
+        float* rm = part == 0 ? rm1 : rm2;
+        float* rv = part == 0 ? rv1 : rv2;
+        float* out = part == 0 ? coef : coef + 4 * Os;
+        float mean, invstd;
+        if (training) {
+            const double m = st[c] / (double)E;
+            double var = st[C + c] / (double)E - m * m;
+            if (var < 0.0) var = 0.0;
+            mean = (float)m;
+            invstd = (float)(1.0 / sqrt(var + (double)eps));
+            if (rm) rm[c] = (1.f - momentum) * rm[c] + momentum * mean;
+            if (rv) rv[c] = (1.f - momentum) * rv[c] + momentum * (float)(E > 1 ? var * ((double)E / (double)(E - 1)) : var);
+        } else {
+            mean = rm[c];
+            invstd = 1.f / sqrtf(rv[c] + eps);
+        }
+        out[c] = g[c] * invstd;
+        out[C + c] = bb[c] - g[c] * mean * invstd;
+        out[2 * C + c] = mean;
+        out[3 * C + c] = invstd;
+    }
+}
+
+__global__ __launch_bounds__(256) void xyzblock_apply_kernel(const float* __restrict__ y_max, const float* __restrict__ y_min,
+                                                             const float* __restrict__ mv, const float* __restrict__ mvn,
+                                                             const float* __restrict__ coef, const float* __restrict__ gate,
+                                                             int64_t P, int64_t N, int Os, int Ov, float slope,
+                                                             float* __restrict__ s_out, float* __restrict__ v_out) {
+    const float* A1 = coef; const float* B1 = coef + Os; const float* Av = coef + 4 * Os; const float* Bv = Av + Ov;
+    const int64_t ts = P * Os, tv = P * 3 * Ov;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < ts + tv; e += (int64_t)gridDim.x * blockDim.x) {
+        if (e < ts) {
+            const int o = (int)(e % Os);
+            const float a = A1[o];
+            const float y = a * (a >= 0.f ? y_max[e] : y_min[e]) + B1[o];
+            s_out[e] = y > 0.f ? y : y * slope;
+        } else {
+            const int64_t q = e - ts;
+            const int c = (int)(q % Ov);
+            const int64_t p = q / (3 * Ov);
+            v_out[q] = gate[(p / N) * Ov + c] * (Av[c] * mv[q] + Bv[c] * mvn[q]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- backward
+// prelude: gy = Gs*lrelu'(y*), red = [sum gy | sum gy*xhat*], dgate, redv = [sum Gv*gate*mv | sum Gv*gate*mvn]
+__global__ __launch_bounds__(256) void xyzblock_bwd_prelude_kernel(
+    const float* __restrict__ gs, const float* __restrict__ gv, const float* __restrict__ y_max, const float* __restrict__ y_min,
+    const float* __restrict__ mv, const float* __restrict__ mvn, const float* __restrict__ coef, const float* __restrict__ gate, int64_t P,
+    int64_t N, int Os, int Ov, float slope, int64_t rows_per_block, float* __restrict__ gy, float* __restrict__ red,
+    float* __restrict__ redv, float* __restrict__ dgate) {
+    const float* A1 = coef; const float* B1 = coef + Os; const float* MY = coef + 2 * Os; const float* IY = coef + 3 * Os;
+    const float* Av = coef + 4 * Os; const float* Bv = Av + Ov;
+    const int64_t p0 = (int64_t)blockIdx.x * rows_per_block, p1 = min(P, p0 + rows_per_block);
+    for (int o = threadIdx.x; o < Os; o += blockDim.x) {
+        const float a = A1[o], bb = B1[o], my = MY[o], iy = IY[o];
+        float r1 = 0.f, r2 = 0.f;
+        for (int64_t p = p0; p < p1; ++p) {
+            const float sel = a >= 0.f ? y_max[p * Os + o] : y_min[p * Os + o];
+            const float y = a * sel + bb;
+            const float g = gs[p * Os + o] * (y > 0.f ? 1.f : slope);
+            gy[p * Os + o] = g;
+            r1 += g;
+            r2 += g * (sel - my) * iy;
+        }
+        atomicAdd(&red[o], r1);
+        atomicAdd(&red[Os + o], r2);
+    }
+    for (int c = threadIdx.x; c < Ov; c += blockDim.x) {
+        const float av = Av[c], bv = Bv[c];
+        float ra = 0.f, rb = 0.f, gsum = 0.f;
+        int64_t cur_b = -1;
+        for (int64_t p = p0; p < p1; ++p) {
+            const int64_t b = p / N;
+            if (b != cur_b) {
+                if (cur_b >= 0) atomicAdd(&dgate[cur_b * Ov + c], gsum);
+                cur_b = b;
+                gsum = 0.f;
+            }
+            const float gt = gate[b * Ov + c];
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd) {
+                const int64_t q = (p * 3 + dd) * Ov + c;
+                const float g = gv[q], a = mv[q], n = mvn[q];
+                gsum += g * (av * a + bv * n);
+                ra += g * gt * a;
+                rb += g * gt * n;
+            }
+        }
+        if (cur_b >= 0) atomicAdd(&dgate[cur_b * Ov + c], gsum);
+        atomicAdd(&redv[c], ra);
+        atomicAdd(&redv[Ov + c], rb);
+    }
+}
+
+// edge pass: parameter gradients only.  gw layout: [W1 (Os*12) | W2 (Ov*2) | W0 (6) | Wz (6)], accumulated with atomics.
+__global__ __launch_bounds__(256) void xyzblock_bwd_kernel(svnet_xyzblock_bwd_desc d, int waves_per_cloud, int points_per_wave) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_g = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t b = wave_g / waves_per_cloud;
+    if (b >= d.B) return;  // wave-uniform
+    const int wi = (int)(wave_g - b * waves_per_cloud);
+    const int p_begin = wi * points_per_wave;
+    const int p_end = min((int)d.N, p_begin + points_per_wave);
+    if (p_begin >= p_end) return;
+    const int Os = d.Os, Ov = d.Ov, k = (int)d.k;
+    const int64_t N = d.N;
+    const float* xb = d.x + b * 3 * N;
+
+    float w0[3][2], wz[3][2];
+    load_small(d.w0, w0);
+    load_small(d.wz, wz);
+    const bool o_lane = lane < Os, v_lane = lane < Ov;
+    const int lo = min(lane, Os - 1), lv = min(lane, Ov - 1);
+    float w1[12];
+#pragma unroll
+    for (int f = 0; f < 12; ++f) w1[f] = o_lane ? d.w1[lane * 12 + f] : 0.f;
+    const float w2a = v_lane ? d.w2[lane * 2 + 0] : 0.f, w2b = v_lane ? d.w2[lane * 2 + 1] : 0.f;
+
+    const float* coef = d.coef;
+    const float a1 = coef[lo], my = coef[2 * Os + lo], iy = coef[3 * Os + lo];
+    const float avc = coef[4 * Os + lv], bvc = coef[4 * Os + Ov + lv];
+    const float m1 = d.bcoef[lo], m2 = d.bcoef[Os + lo], cs = d.bcoef[2 * Os + lo];
+    const float c0 = d.bcoef[3 * Os + lv], c1 = d.bcoef[3 * Os + Ov + lv];
+    const float invk = 1.f / (float)k;
+    const float gt = d.gate[b * Ov + lv] * invk;
+    float gc[6];
+#pragma unroll
+    for (int f = 0; f < 6; ++f) gc[f] = d.gconst[b * 6 + f];
+
+    float gw1[12];
+#pragma unroll
+    for (int f = 0; f < 12; ++f) gw1[f] = 0.f;
+    float gw2a = 0.f, gw2b = 0.f;
+    float gw0[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, gwz[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+
+    for (int p = p_begin; p < p_end; ++p) {
+        const int64_t gp = b * N + p;
+        const float xi[3] = {xb[p], xb[N + p], xb[2 * N + p]};
+        const int slot = (a1 >= 0.f) ? d.slot_max[gp * Os + lo] : d.slot_min[gp * Os + lo];
+        const float gyv = d.gy[gp * Os + lo];
+        const float gv0 = d.gv[(gp * 3 + 0) * Ov + lv] * gt, gv1 = d.gv[(gp * 3 + 1) * Ov + lv] * gt, gv2 = d.gv[(gp * 3 + 2) * Ov + lv] * gt;
+        for (int t = 0; t < k; ++t) {
+            const int64_t j = d.idx[gp * k + t];
+            const float xj[3] = {xb[j], xb[N + j], xb[2 * N + j]};
+            EdgeFeat e;
+            edge_features(xi, xj, w0, wz, e);
+            // ---- scalar path
+            float y = 0.f;
+#pragma unroll
+            for (int f = 0; f < 12; ++f) y = fmaf(w1[f], e.f[f], y);
+            const float g = (slot == t) ? gyv : 0.f;
+            const float xh = (y - my) * iy;
+            const float dyp = o_lane ? cs * (g - m1 - xh * m2) : 0.f;
+            float df[12];
+#pragma unroll
+            for (int f = 0; f < 12; ++f) {
+                gw1[f] = fmaf(dyp, e.f[f], gw1[f]);
+                df[f] = wave_sum(dyp * w1[f]);                 // dL/dfeature f (wave-uniform)
+            }
+#pragma unroll
+            for (int f = 0; f < 6; ++f) df[f] += gc[f];        // gate path: mean over the edges of s
+            // ---- v2s backward for both frames: s[c2*3+jz] = sum_d ve[d][c2] z[d][jz],  z[d][jz] = sum_c ve[d][c] W[jz][c]
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int jz = 0; jz < 3; ++jz)
+#pragma unroll
+                    for (int dd = 0; dd < 3; ++dd) {
+                        const float dz = df[h * 6 + 0 * 3 + jz] * e.ve[dd][0] + df[h * 6 + 1 * 3 + jz] * e.ve[dd][1];
+                        if (h == 0) { gw0[jz][0] = fmaf(dz, e.ve[dd][0], gw0[jz][0]); gw0[jz][1] = fmaf(dz, e.ve[dd][1], gw0[jz][1]); }
+                        else { gwz[jz][0] = fmaf(dz, e.ve[dd][0], gwz[jz][0]); gwz[jz][1] = fmaf(dz, e.ve[dd][1], gwz[jz][1]); }
+                    }
+            }
+            // ---- vector path
+            float vp[3];
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd) vp[dd] = w2a * e.ve[dd][0] + w2b * e.ve[dd][1];
+            const float nv = sqrtf(vp[0] * vp[0] + vp[1] * vp[1] + vp[2] * vp[2]);
+            const float nn = nv + VEPS;
+            const float q = avc + bvc / nn;
+            const float gdot = gv0 * vp[0] + gv1 * vp[1] + gv2 * vp[2];
+            const float dnn = -gdot * bvc / (nn * nn) + c0 + c1 * nn;
+            const float kk = nv > 0.f ? dnn / nv : 0.f;
+            const float gvv[3] = {gv0, gv1, gv2};
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd) {
+                const float dvp = v_lane ? (gvv[dd] * q + kk * vp[dd]) : 0.f;
+                gw2a = fmaf(dvp, e.ve[dd][0], gw2a);
+                gw2b = fmaf(dvp, e.ve[dd][1], gw2b);
+            }
+        }
+    }
+    if (o_lane) {
+#pragma unroll
+        for (int f = 0; f < 12; ++f) atomicAdd(&d.gw[lane * 12 + f], gw1[f]);
+    }
+    if (v_lane) {
+        atomicAdd(&d.gw[Os * 12 + lane * 2 + 0], gw2a);
+        atomicAdd(&d.gw[Os * 12 + lane * 2 + 1], gw2b);
+    }
+    if (lane < 12) {  // the v2s gradients are wave-uniform: lane q publishes element q
+        float val = 0.f;
+#pragma unroll
+        for (int jz = 0; jz < 3; ++jz)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                val = (lane == jz * 2 + c) ? gw0[jz][c] : val;
+                val = (lane == 6 + jz * 2 + c) ? gwz[jz][c] : val;
+            }
+        atomicAdd(&d.gw[Os * 12 + Ov * 2 + lane], val);
+    }
+}
+
+inline void wave_geometry(int64_t B, int64_t N, int& wpc, int& ppw) {
+    wpc = (int)svnet_cdiv(8192, B);
+    if (wpc > N) wpc = (int)N;
+    if (wpc < 1) wpc = 1;
+    ppw = (int)svnet_cdiv(N, wpc);
+    wpc = (int)svnet_cdiv(N, ppw);
+}
+
+}  // namespace
+
+extern "C" int svnet_xyzblock_fwd_f32(const svnet_xyzblock_desc* desc, void* stream) {
+    SVNET_REQUIRE(desc, SVNET_E_ARG, "svnet_xyzblock_fwd_f32: null descriptor");
+    const svnet_xyzblock_desc& d = *desc;
+    SVNET_REQUIRE(d.x && d.idx && d.w0 && d.wz && d.w1 && d.w2 && d.y_max && d.y_min && d.slot_max && d.slot_min && d.mv && d.mvn &&
+                      d.gate_sum, SVNET_E_ARG, "svnet_xyzblock_fwd_f32: null pointer");
+    SVNET_REQUIRE((d.stat_y == nullptr) == (d.stat_v == nullptr), SVNET_E_ARG, "svnet_xyzblock_fwd_f32: pass both stat buffers or none");
+    SVNET_REQUIRE(d.B >= 0 && d.N > 0 && d.k > 0 && d.k <= 255, SVNET_E_ARG, "svnet_xyzblock_fwd_f32: bad sizes");
+    SVNET_REQUIRE(d.Os > 0 && d.Os <= 64 && d.Ov > 0 && d.Ov <= 64, SVNET_E_UNSUPPORTED, "svnet_xyzblock_fwd_f32: needs Os <= 64, Ov <= 64");
+    if (d.B == 0) return SVNET_OK;
+    XyzFwdArgs fa;
+    fa.d = d;
+    wave_geometry(d.B, d.N, fa.waves_per_cloud, fa.points_per_wave);
+    const unsigned grid = (unsigned)svnet_cdiv(d.B * fa.waves_per_cloud, 4);
+    hipLaunchKernelGGL(xyzblock_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, fa);
+    SVNET_CHECK_LAUNCH("xyzblock_fwd_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_xyzblock_coeffs_f32(const double* stat_y, const double* stat_v, int64_t E, int64_t Os, int64_t Ov,
+                                         const float* gamma1, const float* beta1, float* running_mean1, float* running_var1,
+                                         const float* gamma2, const float* beta2, float* running_mean2, float* running_var2,
+                                         int training, float eps, float momentum, float* coef, void* stream) {
+    SVNET_REQUIRE(gamma1 && beta1 && gamma2 && beta2 && coef && E > 0 && Os > 0 && Ov > 0, SVNET_E_ARG, "svnet_xyzblock_coeffs_f32: bad arguments");
+    SVNET_REQUIRE(training ? (stat_y && stat_v) : (running_mean1 && running_var1 && running_mean2 && running_var2), SVNET_E_ARG,
+                  "svnet_xyzblock_coeffs_f32: missing statistics");
+    const int64_t n = Os > Ov ? Os : Ov;
+    hipLaunchKernelGGL(xyzblock_coeffs_kernel, dim3((unsigned)svnet_cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream, stat_y, stat_v, E,
+                       (int)Os, (int)Ov, gamma1, beta1, running_mean1, running_var1, gamma2, beta2, running_mean2, running_var2,
+                       training, eps, momentum, coef);
+    SVNET_CHECK_LAUNCH("xyzblock_coeffs_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_xyzblock_apply_f32(const float* y_max, const float* y_min, const float* mv, const float* mvn, const float* coef,
+                                        const float* gate, int64_t P, int64_t N, int64_t Os, int64_t Ov, float slope, float* s_out,
+                                        float* v_out, void* stream) {
+    SVNET_REQUIRE(y_max && y_min && mv && mvn && coef && gate && s_out && v_out && P >= 0 && N > 0, SVNET_E_ARG, "svnet_xyzblock_apply_f32: bad arguments");
+    if (P == 0) return SVNET_OK;
+    hipLaunchKernelGGL(xyzblock_apply_kernel, dim3(svnet_grid(P * (Os + 3 * Ov), 256)), dim3(256), 0, (hipStream_t)stream, y_max, y_min, mv,
+                       mvn, coef, gate, P, N, (int)Os, (int)Ov, slope, s_out, v_out);
+    SVNET_CHECK_LAUNCH("xyzblock_apply_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_xyzblock_bwd_prelude_f32(const float* gs, const float* gv, const float* y_max, const float* y_min, const float* mv,
+                                              const float* mvn, const float* coef, const float* gate, int64_t P, int64_t N, int64_t Os,
+                                              int64_t Ov, float slope, float* gy, float* red, float* redv, float* dgate, void* stream) {
+    SVNET_REQUIRE(gs && gv && y_max && y_min && mv && mvn && coef && gate && gy && red && redv && dgate, SVNET_E_ARG,
+                  "svnet_xyzblock_bwd_prelude_f32: null pointer");
+    SVNET_REQUIRE(P > 0 && N > 0 && Os > 0 && Ov > 0, SVNET_E_ARG, "svnet_xyzblock_bwd_prelude_f32: bad sizes");
+    int64_t blocks = svnet_cdiv(P, 16);
+    if (blocks > 2048) blocks = 2048;
+    const int64_t rpb = svnet_cdiv(P, blocks);
+    blocks = svnet_cdiv(P, rpb);
+    hipLaunchKernelGGL(xyzblock_bwd_prelude_kernel, dim3((unsigned)blocks), dim3(128), 0, (hipStream_t)stream, gs, gv, y_max, y_min, mv, mvn,
+                       coef, gate, P, N, (int)Os, (int)Ov, slope, rpb, gy, red, redv, dgate);
+    SVNET_CHECK_LAUNCH("xyzblock_bwd_prelude_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_xyzblock_bwd_f32(const svnet_xyzblock_bwd_desc* desc, void* stream) {
+    SVNET_REQUIRE(desc, SVNET_E_ARG, "svnet_xyzblock_bwd_f32: null descriptor");
+    const svnet_xyzblock_bwd_desc& d = *desc;
+    SVNET_REQUIRE(d.x && d.idx && d.w0 && d.wz && d.w1 && d.w2 && d.slot_max && d.slot_min && d.coef && d.bcoef && d.gate && d.gy && d.gv &&
+                      d.gconst && d.gw, SVNET_E_ARG, "svnet_xyzblock_bwd_f32: null pointer");
+    SVNET_REQUIRE(d.B >= 0 && d.N > 0 && d.k > 0 && d.k <= 255, SVNET_E_ARG, "svnet_xyzblock_bwd_f32: bad sizes");
+    SVNET_REQUIRE(d.Os > 0 && d.Os <= 64 && d.Ov > 0 && d.Ov <= 64, SVNET_E_UNSUPPORTED, "svnet_xyzblock_bwd_f32: needs Os <= 64, Ov <= 64");
+    if (d.B == 0) return SVNET_OK;
+    int wpc, ppw;
+    wave_geometry(d.B, d.N, wpc, ppw);
+    const unsigned grid = (unsigned)svnet_cdiv(d.B * wpc, 4);
+    hipLaunchKernelGGL(xyzblock_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d, wpc, ppw);
+    SVNET_CHECK_LAUNCH("xyzblock_bwd_kernel");
+    return SVNET_OK;
+}

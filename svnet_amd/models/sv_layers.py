@@ -19,7 +19,7 @@ import torch.nn.init as init
 import torch.nn.functional as F
 
 from .. import _ops
-from .utils.sv_util import svpool, EdgeFeatures
+from .utils.sv_util import svpool, EdgeFeatures, XyzEdges
 
 EPS = 1e-6
 
@@ -116,6 +116,10 @@ class Vector2Scalar(nn.Module):
         shape of v: B, N_points, [k,] 3, dim
         '''
         assert v.ndim in [3, 4, 5], 'dim of v should be in [4, 5], got {}'.format(v.ndim)
+        if isinstance(v, XyzEdges):
+            if not self.linear.bw and not self.trans_back and tuple(self.linear.weight.shape) == (3, 2):
+                return LazyInitScalar(self, v)
+            v = v.materialize()
         s, z = _ops.V2S.apply(v, self.linear.weight, self.linear.scale if self.linear.bw else None, self.training)
         return (s, z) if self.trans_back else s
 
@@ -135,6 +139,57 @@ class VectorReLU(nn.Module):
         length = torch.linalg.vector_norm(rows, dim=2, keepdim=True).detach()
         threshold = torch.kthvalue(length, kth, dim=1, keepdim=True)[0]
         return torch.where(length > threshold, rows, torch.zeros_like(rows)).view(shape_x)
+
+
+class LazyInitScalar:
+    """Vector2Scalar(2,3) applied to lazy XyzEdges (the `init_scalar` of the DGCNN models): stands for its [B,N,k,6]
+    output; computed on demand, or folded into the fused first-layer kernel by SVBlock + svpool."""
+
+    def __init__(self, v2s, edges):
+        self.v2s, self.edges, self._s = v2s, edges, None
+
+    def materialize(self):
+        if self._s is None:
+            self._s = self.v2s(self.edges.materialize())
+        return self._s
+
+    def __getattr__(self, name):
+        return getattr(self.materialize(), name)
+
+
+class PendingXyzBlock:
+    """SVBlock (fp) applied to (LazyInitScalar, XyzEdges): svpool(max over k) runs the fused first-layer kernel."""
+
+    def __init__(self, block, s_lazy, edges):
+        self.block, self.s_lazy, self.edges, self._out = block, s_lazy, edges, None
+
+    def pooled(self, dim, keepdim, spool):
+        if dim != 2 or spool != 'max' or self._out is not None:
+            return None
+        b, e = self.block, self.edges
+        bn1, bn2 = b.bn1, b.bn2.bn
+        if b.training:
+            bn1.num_batches_tracked.add_(1)
+            bn2.num_batches_tracked.add_(1)
+        s, v = _ops.XyzBlock.apply(
+            e.pts, e.idx, e.k, b.training, self.s_lazy.v2s.linear.weight, b.v2s.linear.weight, b.linear1.weight, bn1.weight,
+            bn1.bias, bn1.running_mean, bn1.running_var, b.linear2.weight, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var,
+            b.gate[0].weight, b.gate[2].weight)
+        return (s.unsqueeze(2), v.unsqueeze(2)) if keepdim else (s, v)
+
+    def materialize(self):
+        if self._out is None:
+            self._out = self.block._forward_rows((self.s_lazy.materialize(), self.edges.materialize()))
+        return self._out
+
+    def __iter__(self):
+        return iter(self.materialize())
+
+    def __getitem__(self, i):
+        return self.materialize()[i]
+
+    def __len__(self):
+        return 2
 
 
 class PendingEdgeBlock:
@@ -220,6 +275,15 @@ class SVBlock(nn.Module):
         '''
         if isinstance(x, EdgeFeatures) and self._can_fuse(x):
             return PendingEdgeBlock(self, x)
+        if isinstance(x, (tuple, list)) and len(x) == 2 and (isinstance(x[0], LazyInitScalar) or isinstance(x[1], XyzEdges)):
+            s, v = x
+            lin1, lin2 = self.linear1, self.linear2
+            if (isinstance(s, LazyInitScalar) and s.edges is v and not (lin1.bw or lin1.ba or lin2.bw or self.v2s.linear.bw)
+                    and lin1.in_features == 12 and lin1.out_features <= 64 and lin2.out_features <= 64 and v.k <= 255
+                    and (self.training or not torch.is_grad_enabled()
+                         or not any(p.requires_grad for p in self.parameters()))):
+                return PendingXyzBlock(self, s, v)
+            x = (s.materialize() if isinstance(s, LazyInitScalar) else s, v.materialize() if isinstance(v, XyzEdges) else v)
         return self._forward_rows(x)
 
     def _forward_rows(self, x):

@@ -45,6 +45,33 @@ class EdgeFeatures:
     def __len__(self):
         return 2
 
+class XyzEdges:
+    """What get_graph_feature returns when edge fusion is on (plain xyz input, dynamic graph): stands for the edge
+    tensor [B,N,k,3,2] = [x_j - x_i, x_i]; `materialize()` builds it, any tensor attribute access does so implicitly.
+    Vector2Scalar / SVBlock / svpool recognise it and run the fused first-layer kernel on (x, idx) instead."""
+
+    def __init__(self, pts, idx, k):
+        self.pts, self.idx, self.k = pts, idx, k          # pts: [B,3,N]
+        self._v = None
+
+    def materialize(self):
+        if self._v is None:
+            self._v = _ops.edge_xyz(self.pts, self.idx, 0)
+        return self._v
+
+    @property
+    def ndim(self):
+        return 5
+
+    @property
+    def shape(self):
+        B, _, N = self.pts.shape
+        return torch.Size((B, N, self.k, 3, 2))
+
+    def __getattr__(self, name):                          # anything else: behave like the tensor
+        return getattr(self.materialize(), name)
+
+
 __all__ = ["knn", "get_graph_feature", "get_graph_feature_cross", "get_graph_feature_sv", "svpool", "svcat",
            "torch", "nn", "F", "np", "math", "os", "sys", "copy", "init"]
 
@@ -61,9 +88,12 @@ def _xyz_edges(x, k, idx, x_coord, mode):
                                   "hot path (no SV model needs them)")
     B, N = x.size(0), x.size(3)
     pts = x.reshape(B, -1, N)
+    dynamic = idx is None and x_coord is None
     if idx is None:
         src = pts if x_coord is None else x_coord.reshape(B, -1, N)
         idx = _ops.knn(src, k)
+    if config.FUSE_EDGE_BLOCKS and dynamic and mode == 0 and pts.size(1) == 3:
+        return XyzEdges(pts.contiguous(), idx, k)
     return _ops.edge_xyz(pts, idx, mode)
 
 

@@ -88,3 +88,66 @@ def test_fused_backward_matches_layerwise(shape, hip_device):
         grads[fuse] = g
     assert set(grads[True]) == set(grads[False])
     compare_case(grads[True], grads[False], 1e-3, "fused vs layerwise backward")
+
+
+# ----------------------------------------------------------------------------- fused FIRST layer (xyz -> init_scalar -> conv1 -> pool)
+
+class _FirstLayer(torch.nn.Module):
+    def __init__(self, out_dims):
+        super().__init__()
+        from svnet_amd.models.sv_layers import SVBlock, Vector2Scalar
+        with contextlib.redirect_stdout(io.StringIO()):
+            self.init_scalar = Vector2Scalar(2, 3)
+            self.conv1 = SVBlock((6, 2), out_dims)
+
+    def forward(self, x, k):
+        from svnet_amd.models.utils.sv_util import get_graph_feature, svpool
+        v = get_graph_feature(x.unsqueeze(1), k=k)
+        return svpool(self.conv1((self.init_scalar(v), v)))
+
+
+def _first_layer_params(out_dims, tag):
+    p = {"init_scalar." + n: t for n, t in H.module_params("Vector2Scalar", (2, 3, False, False), tag + "/v2s").items()}
+    p.update({"conv1." + n: t for n, t in H.module_params("SVBlock", ((6, 2), out_dims, False), tag + "/blk").items()})
+    return p
+
+
+@pytest.mark.parametrize("train", [False, True], ids=["eval", "train"])
+@pytest.mark.parametrize("cfg", [((32, 10), 2, 96, 6), ((32, 16), 1, 150, 40), ((32, 10), 3, 64, 20)], ids=["a", "b", "c"])
+def test_fused_first_layer_matches_layerwise_and_oracle(cfg, train, hip_device):
+    from svnet_amd import config
+    out_dims, B, N, k = cfg
+    params = _first_layer_params(out_dims, "first")
+    x = C.small_cloud(B, N, 5)
+    res = {}
+    for fuse in (True, False):
+        m = _FirstLayer(out_dims)
+        m.load_state_dict(params)
+        m = m.to(hip_device).train(train)
+        old = config.FUSE_EDGE_BLOCKS
+        config.FUSE_EDGE_BLOCKS = fuse
+        try:
+            if train:
+                s, v = m(x.to(hip_device), k)
+                rs, rv = C.t("first/rs", tuple(s.shape)).to(hip_device), C.t("first/rv", tuple(v.shape)).to(hip_device)
+                ((s * rs).sum() + (v * rv).sum()).backward()
+            else:
+                with torch.no_grad():
+                    s, v = m(x.to(hip_device), k)
+        finally:
+            config.FUSE_EDGE_BLOCKS = old
+        r = {"out0": s.detach().cpu().numpy(), "out1": v.detach().cpu().numpy()}
+        if train:
+            r.update({"d:" + n: p.grad.cpu().numpy() for n, p in m.named_parameters()})
+            r.update({"buf:" + n: b.detach().cpu().numpy() for n, b in m.named_buffers() if b.is_floating_point()})
+        res[fuse] = r
+    assert set(res[True]) == set(res[False])
+    compare_case(res[True], res[False], 1e-4 if not train else 1e-3, "fused first layer vs layerwise")
+    # oracle forward on the same input
+    P = {n: t.clone() for n, t in params.items()}
+    ctx = sv_ref.Ctx(train=train)
+    with torch.no_grad():
+        ve = sv_ref.graph_feature(x.unsqueeze(1), k=k)
+        s0 = sv_ref.vector2scalar(ve, P, "init_scalar")
+        os_, ov = sv_ref.svpool(sv_ref.svblock((s0, ve), P, "conv1", False, ctx))
+    compare_case({"out0": res[True]["out0"], "out1": res[True]["out1"]}, {"out0": os_.numpy(), "out1": ov.numpy()}, 1e-4, "fused first layer vs oracle")
