@@ -254,12 +254,12 @@ __global__ __launch_bounds__(256) void xyzblock_bwd_prelude_kernel(
 __global__ __launch_bounds__(256) void xyzblock_bwd_kernel(svnet_xyzblock_bwd_desc d, int waves_per_cloud, int points_per_wave) {
     const int lane = threadIdx.x & 63;
     const int64_t wave_g = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t b = wave_g / waves_per_cloud;
-    if (b >= d.B) return;  // wave-uniform
-    const int wi = (int)(wave_g - b * waves_per_cloud);
+    const int64_t bq = wave_g / waves_per_cloud;
+    const int64_t b = bq < d.B ? bq : d.B - 1;
+    const int wi = (int)(wave_g - bq * waves_per_cloud);
     const int p_begin = wi * points_per_wave;
-    const int p_end = min((int)d.N, p_begin + points_per_wave);
-    if (p_begin >= p_end) return;
+    const int p_end = (bq < d.B) ? min((int)d.N, p_begin + points_per_wave) : p_begin;   // idle waves still reach the barriers
+    const bool live = p_begin < p_end;
     const int Os = d.Os, Ov = d.Ov, k = (int)d.k;
     const int64_t N = d.N;
     const float* xb = d.x + b * 3 * N;
@@ -289,7 +289,11 @@ __global__ __launch_bounds__(256) void xyzblock_bwd_kernel(svnet_xyzblock_bwd_de
 #pragma unroll
     for (int f = 0; f < 12; ++f) gw1[f] = 0.f;
     float gw2a = 0.f, gw2b = 0.f;
-    float gw0[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, gwz[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    // The v2s weight gradients are linear in dL/dfeature = sum_o dyp[o] W1[o][:] (+ gate constants), so instead of a
+    // wave reduction per edge each lane keeps  M[c2][c] = sum_e dyp[e,o] * Q_e[c2][c],  Q_e = sum_d ve[d][c2] ve[d][c],
+    // and the reduction over the output channels happens ONCE per wave at the end.
+    float m00 = 0.f, m01 = 0.f, m11 = 0.f;     // per lane (output channel o)
+    float q00 = 0.f, q01 = 0.f, q11 = 0.f;     // wave-uniform sums of Q_e (for the gate-constant term)
 
     for (int p = p_begin; p < p_end; ++p) {
         const int64_t gp = b * N + p;
@@ -309,26 +313,13 @@ __global__ __launch_bounds__(256) void xyzblock_bwd_kernel(svnet_xyzblock_bwd_de
             const float g = (slot == t) ? gyv : 0.f;
             const float xh = (y - my) * iy;
             const float dyp = o_lane ? cs * (g - m1 - xh * m2) : 0.f;
-            float df[12];
 #pragma unroll
-            for (int f = 0; f < 12; ++f) {
-                gw1[f] = fmaf(dyp, e.f[f], gw1[f]);
-                df[f] = wave_sum(dyp * w1[f]);                 // dL/dfeature f (wave-uniform)
-            }
-#pragma unroll
-            for (int f = 0; f < 6; ++f) df[f] += gc[f];        // gate path: mean over the edges of s
-            // ---- v2s backward for both frames: s[c2*3+jz] = sum_d ve[d][c2] z[d][jz],  z[d][jz] = sum_c ve[d][c] W[jz][c]
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                for (int jz = 0; jz < 3; ++jz)
-#pragma unroll
-                    for (int dd = 0; dd < 3; ++dd) {
-                        const float dz = df[h * 6 + 0 * 3 + jz] * e.ve[dd][0] + df[h * 6 + 1 * 3 + jz] * e.ve[dd][1];
-                        if (h == 0) { gw0[jz][0] = fmaf(dz, e.ve[dd][0], gw0[jz][0]); gw0[jz][1] = fmaf(dz, e.ve[dd][1], gw0[jz][1]); }
-                        else { gwz[jz][0] = fmaf(dz, e.ve[dd][0], gwz[jz][0]); gwz[jz][1] = fmaf(dz, e.ve[dd][1], gwz[jz][1]); }
-                    }
-            }
+            for (int f = 0; f < 12; ++f) gw1[f] = fmaf(dyp, e.f[f], gw1[f]);
+            const float e00 = e.ve[0][0] * e.ve[0][0] + e.ve[1][0] * e.ve[1][0] + e.ve[2][0] * e.ve[2][0];
+            const float e01 = e.ve[0][0] * e.ve[0][1] + e.ve[1][0] * e.ve[1][1] + e.ve[2][0] * e.ve[2][1];
+            const float e11 = e.ve[0][1] * e.ve[0][1] + e.ve[1][1] * e.ve[1][1] + e.ve[2][1] * e.ve[2][1];
+            m00 = fmaf(dyp, e00, m00); m01 = fmaf(dyp, e01, m01); m11 = fmaf(dyp, e11, m11);
+            q00 += e00; q01 += e01; q11 += e11;
             // ---- vector path
             float vp[3];
 #pragma unroll
@@ -348,24 +339,42 @@ __global__ __launch_bounds__(256) void xyzblock_bwd_kernel(svnet_xyzblock_bwd_de
             }
         }
     }
-    if (o_lane) {
+    // ---- every wave of the grid adds into the same few hundred addresses: combine the workgroup's four waves in LDS
+    // first and issue one set of global atomics per workgroup (same-address float atomics serialise at the memory side)
+    __shared__ float red[64 * 12 + 64 * 2 + 12];
+    const int GW = Os * 12 + Ov * 2 + 12;
+    for (int i = threadIdx.x; i < GW; i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
+    if (live) {
+        if (o_lane) {
 #pragma unroll
-        for (int f = 0; f < 12; ++f) atomicAdd(&d.gw[lane * 12 + f], gw1[f]);
+            for (int f = 0; f < 12; ++f) atomicAdd(&red[lane * 12 + f], gw1[f]);
+        }
+        if (v_lane) {
+            atomicAdd(&red[Os * 12 + lane * 2 + 0], gw2a);
+            atomicAdd(&red[Os * 12 + lane * 2 + 1], gw2b);
+        }
+        // dW[jz][c] = sum_c2 ( sum_o W1[o][h*6 + c2*3 + jz] * M_o[c2][c]  +  gc[c2*3+jz] * Qsum[c2][c] (frame 0 only) )
+        const float mm[2][2] = {{m00, m01}, {m01, m11}};
+        const float qq[2][2] = {{q00, q01}, {q01, q11}};
+        float mine = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int jz = 0; jz < 3; ++jz)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    float part = w1[h * 6 + 0 * 3 + jz] * mm[0][c] + w1[h * 6 + 1 * 3 + jz] * mm[1][c];
+                    float tot = wave_sum(part);
+                    if (h == 0) tot += gc[0 * 3 + jz] * qq[0][c] + gc[1 * 3 + jz] * qq[1][c];
+                    mine = (lane == h * 6 + jz * 2 + c) ? tot : mine;
+                }
+        if (lane < 12) atomicAdd(&red[Os * 12 + Ov * 2 + lane], mine);
     }
-    if (v_lane) {
-        atomicAdd(&d.gw[Os * 12 + lane * 2 + 0], gw2a);
-        atomicAdd(&d.gw[Os * 12 + lane * 2 + 1], gw2b);
-    }
-    if (lane < 12) {  // the v2s gradients are wave-uniform: lane q publishes element q
-        float val = 0.f;
-#pragma unroll
-        for (int jz = 0; jz < 3; ++jz)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                val = (lane == jz * 2 + c) ? gw0[jz][c] : val;
-                val = (lane == 6 + jz * 2 + c) ? gwz[jz][c] : val;
-            }
-        atomicAdd(&d.gw[Os * 12 + Ov * 2 + lane], val);
+    __syncthreads();
+    for (int i = threadIdx.x; i < GW; i += blockDim.x) {
+        const float v = red[i];
+        if (v != 0.f) atomicAdd(&d.gw[i], v);
     }
 }
 
@@ -447,8 +456,11 @@ extern "C" int svnet_xyzblock_bwd_f32(const svnet_xyzblock_bwd_desc* desc, void*
     SVNET_REQUIRE(d.B >= 0 && d.N > 0 && d.k > 0 && d.k <= 255, SVNET_E_ARG, "svnet_xyzblock_bwd_f32: bad sizes");
     SVNET_REQUIRE(d.Os > 0 && d.Os <= 64 && d.Ov > 0 && d.Ov <= 64, SVNET_E_UNSUPPORTED, "svnet_xyzblock_bwd_f32: needs Os <= 64, Ov <= 64");
     if (d.B == 0) return SVNET_OK;
-    int wpc, ppw;
-    wave_geometry(d.B, d.N, wpc, ppw);
+    int wpc = (int)svnet_cdiv(4096, d.B);                       // ~4096 waves = 1024 workgroups, one flush each
+    if (wpc > d.N) wpc = (int)d.N;
+    if (wpc < 1) wpc = 1;
+    const int ppw = (int)svnet_cdiv(d.N, wpc);
+    wpc = (int)svnet_cdiv(d.N, ppw);
     const unsigned grid = (unsigned)svnet_cdiv(d.B * wpc, 4);
     hipLaunchKernelGGL(xyzblock_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d, wpc, ppw);
     SVNET_CHECK_LAUNCH("xyzblock_bwd_kernel");
