@@ -79,11 +79,11 @@ __global__ __launch_bounds__(256) void edgeblock_fwd_kernel(FwdArgs fa) {
         blk = ((slot / bpc) * 8 + xcd) * bpc + (slot % bpc);
     }
     const int64_t wave_g = blk * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // uniform: scalar loads / SGPR addressing
-    const int64_t b = wave_g / fa.waves_per_cloud;
-    if (b >= d.B) return;  // wave-uniform, no barriers in this kernel
-    const int wi = (int)(wave_g - b * fa.waves_per_cloud);
+    const int64_t bq = wave_g / fa.waves_per_cloud;
+    const int64_t b = bq < d.B ? bq : d.B - 1;                 // idle waves keep valid addresses and reach the barriers
+    const int wi = (int)(wave_g - bq * fa.waves_per_cloud);
     const int p_begin = wi * fa.points_per_wave;
-    const int p_end = min((int)d.N, p_begin + fa.points_per_wave);
+    const int p_end = bq < d.B ? min((int)d.N, p_begin + fa.points_per_wave) : p_begin;
     const int Cs = d.Cs, Cv = d.Cv, Os = d.Os, Ov = d.Ov, k = (int)d.k;
 
     // my output channels' weight words
@@ -217,25 +217,37 @@ __global__ __launch_bounds__(256) void edgeblock_fwd_kernel(FwdArgs fa) {
             }
         }
     }
-    if (p_begin < p_end) {
-        if (d.stat_n) {
+    // ---- batch statistics: all waves of the grid add into the same 2*Os + 2*Ov addresses, so the workgroup's four
+    // waves are combined in LDS first (same-address atomics serialise at the memory side)
+    __shared__ unsigned long long red_n[2 * 128];
+    __shared__ double red_v[2 * 64];
+    if (d.stat_n) {
+        for (int i = threadIdx.x; i < 2 * Os; i += blockDim.x) red_n[i] = 0ull;
+        for (int i = threadIdx.x; i < 2 * Ov; i += blockDim.x) red_v[i] = 0.0;
+        __syncthreads();
+        if (p_begin < p_end) {
 #pragma unroll
             for (int op = 0; op < OP; ++op) {
                 const int o = lane + 64 * op;
                 if (o < Os) {
-                    atomicAdd(reinterpret_cast<unsigned long long*>(d.stat_n) + o, (unsigned long long)sn[op]);
-                    atomicAdd(reinterpret_cast<unsigned long long*>(d.stat_n) + Os + o, (unsigned long long)sn2[op]);
+                    atomicAdd(&red_n[o], (unsigned long long)sn[op]);
+                    atomicAdd(&red_n[Os + o], (unsigned long long)sn2[op]);
                 }
             }
             if (o_lane) {
-                atomicAdd(&d.stat_v[lane], sv1);
-                atomicAdd(&d.stat_v[Ov + lane], sv2);
+                atomicAdd(&red_v[lane], sv1);
+                atomicAdd(&red_v[Ov + lane], sv2);
             }
         }
-        if (s_lane) {
-            atomicAdd(&d.gate_sum[b * 2 * Cs + lane], gs_diff);
-            atomicAdd(&d.gate_sum[b * 2 * Cs + Cs + lane], gs_cen * (float)k);
-        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * Os; i += blockDim.x)
+            if (red_n[i] != 0ull) atomicAdd(reinterpret_cast<unsigned long long*>(d.stat_n) + i, red_n[i]);
+        for (int i = threadIdx.x; i < 2 * Ov; i += blockDim.x)
+            if (red_v[i] != 0.0) atomicAdd(&d.stat_v[i], red_v[i]);
+    }
+    if (p_begin < p_end && s_lane) {
+        atomicAdd(&d.gate_sum[b * 2 * Cs + lane], gs_diff);
+        atomicAdd(&d.gate_sum[b * 2 * Cs + Cs + lane], gs_cen * (float)k);
     }
 }
 

@@ -536,14 +536,25 @@ __global__ __launch_bounds__(256, (OP == 1 ? 3 : 2)) void edgeblock_bwd_kernel(s
         }
         if (cur_p >= 0) SVNET_FLUSH_POINT(cur_p);
 #undef SVNET_FLUSH_POINT
+        // dL/dbeta: 320 addresses shared by the whole grid -> combine the four waves in LDS, one atomic per column
+        // per workgroup (same-address float atomics serialise at the memory side)
+        __syncthreads();                                     // every wave is done with dxl
+        float* red = dxl;
+        for (int i = tid; i < NCOL; i += 256) red[i] = 0.f;
+        __syncthreads();
         if (s_lane) {
-            ATOMIC_ADD(&d.dbeta_perm[lane], dbd);
-            ATOMIC_ADD(&d.dbeta_perm[64 + lane], dbc);
+            ATOMIC_ADD(&red[lane], dbd);
+            ATOMIC_ADD(&red[64 + lane], dbc);
         }
         if (v2_lane) {
-            ATOMIC_ADD(&d.dbeta_perm[128 + lane], dbv0);
-            ATOMIC_ADD(&d.dbeta_perm[192 + lane], dbv1);
-            ATOMIC_ADD(&d.dbeta_perm[256 + lane], dbv2);
+            ATOMIC_ADD(&red[128 + lane], dbv0);
+            ATOMIC_ADD(&red[192 + lane], dbv1);
+            ATOMIC_ADD(&red[256 + lane], dbv2);
+        }
+        __syncthreads();
+        for (int i = tid; i < NCOL; i += 256) {
+            const float v = red[i];
+            if (v != 0.f) ATOMIC_ADD(&d.dbeta_perm[i], v);
         }
     }
 }

@@ -61,11 +61,11 @@ __global__ __launch_bounds__(256) void xyzblock_fwd_kernel(XyzFwdArgs fa) {
     const svnet_xyzblock_desc& d = fa.d;
     const int lane = threadIdx.x & 63;
     const int64_t wave_g = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t b = wave_g / fa.waves_per_cloud;
-    if (b >= d.B) return;  // wave-uniform
-    const int wi = (int)(wave_g - b * fa.waves_per_cloud);
+    const int64_t bq = wave_g / fa.waves_per_cloud;
+    const int64_t b = bq < d.B ? bq : d.B - 1;                 // idle waves keep valid addresses and reach the barriers
+    const int wi = (int)(wave_g - bq * fa.waves_per_cloud);
     const int p_begin = wi * fa.points_per_wave;
-    const int p_end = min((int)d.N, p_begin + fa.points_per_wave);
+    const int p_end = bq < d.B ? min((int)d.N, p_begin + fa.points_per_wave) : p_begin;
     const int Os = d.Os, Ov = d.Ov, k = (int)d.k;
     const int64_t N = d.N;
     const float* xb = d.x + b * 3 * N;
@@ -127,17 +127,26 @@ __global__ __launch_bounds__(256) void xyzblock_fwd_kernel(XyzFwdArgs fa) {
             }
         }
     }
-    if (p_begin < p_end) {
-        if (d.stat_y) {
-            if (o_lane) { atomicAdd(&d.stat_y[lane], sy1); atomicAdd(&d.stat_y[Os + lane], sy2); }
-            if (v_lane) { atomicAdd(&d.stat_v[lane], sv1); atomicAdd(&d.stat_v[Ov + lane], sv2); }
+    // ---- batch statistics: combine the workgroup's waves in LDS before touching the (grid-shared) global sums
+    __shared__ double red_s[2 * 64 + 2 * 64];
+    if (d.stat_y) {
+        for (int i = threadIdx.x; i < 2 * Os + 2 * Ov; i += blockDim.x) red_s[i] = 0.0;
+        __syncthreads();
+        if (p_begin < p_end) {
+            if (o_lane) { atomicAdd(&red_s[lane], sy1); atomicAdd(&red_s[Os + lane], sy2); }
+            if (v_lane) { atomicAdd(&red_s[2 * Os + lane], sv1); atomicAdd(&red_s[2 * Os + Ov + lane], sv2); }
         }
-        if (lane < 6) {
-            float val = gsum[0];
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * Os + 2 * Ov; i += blockDim.x) {
+            const double v = red_s[i];
+            if (v != 0.0) atomicAdd(i < 2 * Os ? &d.stat_y[i] : &d.stat_v[i - 2 * Os], v);
+        }
+    }
+    if (p_begin < p_end && lane < 6) {
+        float val = gsum[0];
 #pragma unroll
-            for (int f = 1; f < 6; ++f) val = (lane == f) ? gsum[f] : val;
-            atomicAdd(&d.gate_sum[b * 6 + lane], val);
-        }
+        for (int f = 1; f < 6; ++f) val = (lane == f) ? gsum[f] : val;
+        atomicAdd(&d.gate_sum[b * 6 + lane], val);
     }
 }
 
