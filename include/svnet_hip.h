@@ -275,9 +275,10 @@ int svnet_vbn_bwd_apply_f32(const float* g, const float* v, const float* mean, c
 
 /* ------------------------------------------------------------------ pooling (sv_util.py:118-132 svpool; adaptive pools of sv_dgcnn_cls.py:72-73)
  * x: [outer, R, inner] -> out [outer, inner].  mode 0 = max (argmax int32 saved, first index on ties),
- * mode 1 = mean.                                                                                      */
+ * mode 1 = mean.  workspace (optional, outer*inner*8 bytes): lets a long max-reduction with few outputs (pooling over
+ * the N points) be split over workgroups.  NaN inputs are not supported on the split path.               */
 int svnet_pool_fwd_f32(const float* x, int64_t outer, int64_t R, int64_t inner, int mode, float* out, int32_t* argmax,
-                       void* stream);
+                       void* workspace, size_t workspace_bytes, void* stream);
 int svnet_pool_bwd_f32(const float* g, const int32_t* argmax, int64_t outer, int64_t R, int64_t inner, int mode,
                        float* dx, void* stream);
 

@@ -402,7 +402,8 @@ def pool_raw(x, outer, R, inner, mode):
     """x contiguous viewed as [outer,R,inner] -> (out [outer,inner], argmax int32 or None)."""
     out = torch.empty((outer, inner), dtype=torch.float32, device=x.device)
     arg = torch.empty((outer, inner), dtype=torch.int32, device=x.device) if mode == 0 else None
-    call("svnet_pool_fwd_f32", _p(x), outer, R, inner, mode, _p(out), _p(arg), _stream())
+    ws = torch.empty((outer * inner,), dtype=torch.int64, device=x.device) if (mode == 0 and R >= 256 and outer * inner < 65536) else None
+    call("svnet_pool_fwd_f32", _p(x), outer, R, inner, mode, _p(out), _p(arg), _p(ws), 0 if ws is None else ws.numel() * 8, _stream())
     return out, arg
 
 

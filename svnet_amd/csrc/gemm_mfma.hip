@@ -182,6 +182,7 @@ struct TnArgs {
     int64_t M; int P, Q;
     int64_t rows_per_block;             // multiple of 256
     int ptiles_per_block;               // p tiles (32 wide) handled by the 4 waves of a workgroup: 1, 2 or 4
+    int lds_reduce;                     // combine the row-splitting waves in LDS before the global atomics
     float alpha;
 };
 
@@ -258,6 +259,24 @@ __global__ __launch_bounds__(256) void mfma_tn_kernel(TnArgs a) {
             }
         }
     }
+    // Waves that split the row range of one p tile (narrow P) first combine their partial tiles in LDS: the output
+    // matrix is tiny and shared by the whole grid, and same-address float atomics serialise at the memory side.
+    if (a.lds_reduce) {   // uniform; every wave of the workgroup is live in this configuration
+        extern __shared__ float tnred[];                     // [nsub-1][NQ][16][64]
+        if (sub > 0) {
+#pragma unroll
+            for (int t = 0; t < NQ; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tnred[(((sub - 1) * ptw + (wave % ptw)) * NQ + t) * 1024 + i * 64 + lane] = acc[t][i];
+        }
+        __syncthreads();
+        if (sub > 0) return;
+        for (int s2 = 1; s2 < nsub; ++s2)
+#pragma unroll
+            for (int t = 0; t < NQ; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[t][i] += tnred[(((s2 - 1) * ptw + (wave % ptw)) * NQ + t) * 1024 + i * 64 + lane];
+    }
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
         const int q = q0 + t * 32 + r;  // D col = lane & 31  <-> B operand column (q)
@@ -303,7 +322,10 @@ void launch_tn(TnArgs a, hipStream_t st) {
     if (rpb < 256) rpb = 256;
     a.rows_per_block = rpb;
     const int64_t gx = svnet_cdiv(a.M, rpb);
-    hipLaunchKernelGGL((mfma_tn_kernel<NQ, BMODE>), dim3((unsigned)gx, (unsigned)gy, (unsigned)gz), dim3(256), 0, st, a);
+    const int nsub = 4 / a.ptiles_per_block;
+    const size_t lds = (size_t)(nsub - 1) * a.ptiles_per_block * NQ * 1024 * sizeof(float);
+    a.lds_reduce = (nsub > 1 && ptiles == a.ptiles_per_block && lds <= 64 * 1024) ? 1 : 0;
+    hipLaunchKernelGGL((mfma_tn_kernel<NQ, BMODE>), dim3((unsigned)gx, (unsigned)gy, (unsigned)gz), dim3(256), a.lds_reduce ? lds : 0, st, a);
 }
 
 }  // namespace
@@ -337,7 +359,7 @@ int svnet_mfma_tn(const float* A, int64_t lda, const float* B, int64_t ldb, cons
     if (M == 0) return SVNET_OK;
     TnArgs a;
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.b_sign = b_sign; a.b_nz = b_nz;
-    a.C = C; a.c_ps = c_ps; a.c_qs = c_qs; a.M = M; a.P = (int)P; a.Q = (int)Q; a.alpha = alpha; a.rows_per_block = 0;
+    a.C = C; a.c_ps = c_ps; a.c_qs = c_qs; a.M = M; a.P = (int)P; a.Q = (int)Q; a.alpha = alpha; a.rows_per_block = 0; a.lds_reduce = 0;
     const bool tern = b_sign != nullptr;
     if (Q <= 32) { if (tern) launch_tn<1, 1>(a, st); else launch_tn<1, 0>(a, st); }
     else if (Q <= 64) { if (tern) launch_tn<2, 1>(a, st); else launch_tn<2, 0>(a, st); }

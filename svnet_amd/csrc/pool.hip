@@ -52,6 +52,40 @@ __global__ __launch_bounds__(256) void pool_mean_split_kernel(const float* __res
     }
 }
 
+// max with a long reduced axis: grid (chunks, outer); each (o,i) keeps one packed 64-bit key
+//   key = (order-preserving bits of the value) << 32 | (0xFFFFFFFF - r)      -> atomicMax = largest value, first index
+// in `keys` (pre-filled with 0 by the caller's memset); a second tiny kernel unpacks value and arg-max.
+__device__ __forceinline__ unsigned long long pack_key(float v, int64_t r) {
+    uint32_t u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)r);
+}
+__global__ __launch_bounds__(256) void pool_max_split_kernel(const float* __restrict__ x, int64_t R, int64_t inner,
+                                                             int64_t rows_per_chunk, unsigned long long* __restrict__ keys) {
+    const int64_t o = blockIdx.y;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+    for (int64_t i = threadIdx.x; i < inner; i += blockDim.x) {
+        const float* p = x + o * R * inner + i;
+        float best = p[r0 * inner];
+        int64_t bi = r0;
+        for (int64_t r = r0 + 1; r < r1; ++r) {
+            const float v = p[r * inner];
+            if (v > best) { best = v; bi = r; }
+        }
+        atomicMax(&keys[o * inner + i], pack_key(best, bi));
+    }
+}
+__global__ __launch_bounds__(256) void pool_max_unpack_kernel(const unsigned long long* __restrict__ keys, int64_t total,
+                                                              float* __restrict__ out, int32_t* __restrict__ argmax) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long kk = keys[e];
+        uint32_t u = (uint32_t)(kk >> 32);
+        u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+        out[e] = __uint_as_float(u);
+        if (argmax) argmax[e] = (int32_t)(0xFFFFFFFFu - (uint32_t)(kk & 0xFFFFFFFFull));
+    }
+}
+
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ g, const int32_t* __restrict__ argmax,
                                                        int64_t outer, int64_t R, int64_t inner, int mode,
                                                        float* __restrict__ dx) {
@@ -125,7 +159,7 @@ __global__ __launch_bounds__(256) void smooth_ce_kernel(const float* __restrict_
 }  // namespace
 
 extern "C" int svnet_pool_fwd_f32(const float* x, int64_t outer, int64_t R, int64_t inner, int mode, float* out, int32_t* argmax,
-                                  void* stream) {
+                                  void* workspace, size_t workspace_bytes, void* stream) {
     SVNET_REQUIRE(x && out && outer >= 0 && R > 0 && inner > 0 && (mode == 0 || mode == 1), SVNET_E_ARG, "svnet_pool_fwd_f32: bad arguments");
     if (outer == 0) return SVNET_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -141,6 +175,21 @@ extern "C" int svnet_pool_fwd_f32(const float* x, int64_t outer, int64_t R, int6
         const int block = inner >= 256 ? 256 : (inner >= 128 ? 128 : 64);
         hipLaunchKernelGGL(pool_mean_split_kernel, dim3((unsigned)chunks, (unsigned)outer), dim3(block), 0, st, x, R, inner, rpc, out);
         SVNET_CHECK_LAUNCH("pool_mean_split_kernel");
+        return SVNET_OK;
+    }
+    if (mode == 0 && R >= 256 && total < 256 * 256 && workspace && workspace_bytes >= (size_t)total * 8 && outer <= 65535) {
+        // long max-reduction with few outputs (point pooling over N): split the rows over workgroups
+        unsigned long long* keys = (unsigned long long*)workspace;
+        hipError_t e = hipMemsetAsync(keys, 0, sizeof(unsigned long long) * total, st);
+        SVNET_REQUIRE(e == hipSuccess, SVNET_E_LAUNCH, "svnet_pool_fwd_f32: memset failed");
+        int64_t chunks = svnet_cdiv(256 * 8, outer);
+        if (chunks > svnet_cdiv(R, 32)) chunks = svnet_cdiv(R, 32);
+        const int64_t rpc = svnet_cdiv(R, chunks);
+        chunks = svnet_cdiv(R, rpc);
+        hipLaunchKernelGGL(pool_max_split_kernel, dim3((unsigned)chunks, (unsigned)outer), dim3(256), 0, st, x, R, inner, rpc, keys);
+        SVNET_CHECK_LAUNCH("pool_max_split_kernel");
+        hipLaunchKernelGGL(pool_max_unpack_kernel, dim3(svnet_grid(total, 256)), dim3(256), 0, st, keys, total, out, argmax);
+        SVNET_CHECK_LAUNCH("pool_max_unpack_kernel");
         return SVNET_OK;
     }
     hipLaunchKernelGGL(pool_fwd_kernel, dim3(svnet_grid(total, 256, 256 * 32)), dim3(256), 0, st, x, outer, R, inner, mode, out, argmax);
