@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--roofline-kernel", default="svnet_edge_diffcat_fwd_f32")
+    ap.add_argument("--roofline-kernel", default="svnet_edgeblock_bwd_f32")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -158,22 +158,26 @@ def main():
 
     if rank == 0:
         clouds = B_PER_GPU * world * args.steps
-        # algorithmic bytes of one diffcat launch are shape dependent: report the LARGEST launch of the step (conv4's v_e / s_e)
+        # Dominant kernel of the step: the fused edge-block backward of conv4 (edgeblock_bwd_kernel<2>, one launch per
+        # step; the entry point is called for conv4, conv3, conv2 in that order).  Algorithmic HBM bytes of that launch
+        # (DESIGN.md §4): point tables + neighbour ids + pooled-edge operands read once, dL/dy and the ternary planes
+        # written once for the weight-gradient GEMM, point-level gradients written once.
         ms = timer.elapsed_ms()
         per_launch = None
         if ms:
             E = B_PER_GPU * N_POINTS * K_NN
             P_ = B_PER_GPU * N_POINTS
-            # launches per fwd_bwd in order: (s,v) for conv2, conv3, conv4 -> take the conv4 vector launch (G=3,F=42)
-            n_per_step = 6
-            v4 = [ms[i] for i in range(5, len(ms), n_per_step)]
-            dur = sum(v4) / len(v4) * 1e-3
-            F = 3 * 42
-            alg = P_ * F * 4 + E * 8 + E * 2 * F * 4                 # read table + read idx + write edges
+            Cs, Cv, Os, Ov = 64, 21, 128, 42
+            conv4 = [ms[i] for i in range(0, len(ms), 3)]
+            dur = sum(conv4) / len(conv4) * 1e-3
+            reads = P_ * 4 * (Cs + 3 * Cv + 18 + 6 * Ov) + E * 8 + P_ * Os * (1 + 4) + P_ * 3 * Ov * 4
+            writes = E * Os * 4 + 2 * (E // 8) * 320 + P_ * 4 * (Cs + 3 * Cv + 2 * 3 * Ov + 18)
+            alg = reads + writes
             per_launch = {"bound": "hbm", "achieved": round(alg / dur / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(alg / dur / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                          "kernel": "diffcat_fwd_kernel (conv4 v_e, G=3 F=42)", "avg_launch_us": round(dur * 1e6, 1),
-                          "algorithmic_bytes": alg}
+                          "kernel": "edgeblock_bwd_kernel<2> (conv4: Cs=64 Cv=21 -> Os=128 Ov=42)", "avg_launch_us": round(dur * 1e6, 1),
+                          "algorithmic_bytes": alg,
+                          "note": "latency/atomic-bound, not bandwidth-bound: 8 float-atomic row segments per edge; see DESIGN.md"}
         out = {
             "metric": "point-clouds/sec fwd+bwd, sv_dgcnn_cls B=32 N=1024 k=20",
             "value": round(clouds / elapsed, 2), "unit": "point-clouds/sec", "n_gpus": world, "steps": args.steps,
