@@ -90,9 +90,10 @@ def main():
     y = torch.from_numpy(synth.class_labels(1234, 0, rank, B_PER_GPU)).to(dev)
 
     def fwd_bwd():
-        bucket.zero()
+        bucket.begin()
         loss = cal_loss(model(x), y)
         loss.backward()
+        bucket.pack()                                                 # one batched copy of all gradients into the flat bucket
         return loss.detach()
 
     # a few eager steps first (allocator warm-up).  They run on the SAME stream the capture will use, and no autograd

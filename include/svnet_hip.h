@@ -106,9 +106,9 @@ int svnet_binlinear_fwd_f32(const float* x, int64_t ldx, const float* beta, cons
                             const uint64_t* w_nz, const float* scale, const float* bias, int64_t M, int64_t K,
                             int64_t O, float* y, uint64_t* x_sign, uint64_t* x_nz, uint64_t* x_ste, void* stream);
 /* Chain rule from GX[o,k] = sum_m g[m,o] x_eff[m,k] to the parameters of a bw layer (App. C2):
- *   dW[o,k] = scale[o]*GX[o,k]*[|W[o,k]|<=1.2],  dscale[o] = sum_k w_b[o,k]*GX[o,k].  dW/dscale are ACCUMULATED. */
+ *   dW[o,k] = scale[o]*GX[o,k]*[|W[o,k]|<=1.2],  dscale[o] = sum_k w_b[o,k]*GX[o,k];  accumulate != 0 adds to dW/dscale. */
 int svnet_binweight_grad_f32(const float* GX, const float* W, const float* scale, int64_t O, int64_t K,
-                             float* dW, float* dscale, void* stream);
+                             float* dW, float* dscale, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------ fused edge block (tier 2)
  * One pass over the edges of a BINARIZED edge layer, never materialising an edge tensor:
@@ -135,13 +135,19 @@ typedef struct svnet_edgeblock_desc {
 } svnet_edgeblock_desc;
 int svnet_edgeblock_prepare_f32(const float* W, const float* beta, int64_t Os, int64_t Cs, int64_t Cv, uint64_t* w_sign,
                                 uint64_t* w_nz, float* beta_perm /*[5*64]*/, void* stream);
+/* The binarized weights of the two per-point products in one table: wv [2Ov+6, Cv] = [sign(W2[:, :Cv]) ; sign(W2[:, Cv:]) ;
+ * sign(Wz[:, :Cv]) ; sign(Wz[:, Cv:])], scv [2Ov+6] = [scale2, scale2, scalez, scalez]  (ut = v.wv[:2Ov]^T*scv, zz = v.wv[2Ov:]^T*scv). */
+int svnet_edgeblock_prepare_vec_f32(const float* W2, const float* scale2, const float* Wz, const float* scalez, int64_t Ov,
+                                    int64_t Cv, float* wv, float* scv, void* stream);
 int svnet_edgeblock_fwd_f32(const svnet_edgeblock_desc* desc, void* stream);
 /* coef [4*Os + 4*Ov] = [A1 | B1 | mean_y | invstd_y | Av | Bv | mean_n' | invstd_n']: BatchNorm folded into
  * y = A1*n + B1 and q = Av + Bv/n'; training != 0 uses the batch sums (E = B*N*k edges) and updates running_*.   */
 int svnet_edgeblock_coeffs_f32(const int64_t* stat_n, const double* stat_v, int64_t E, int64_t Os, int64_t Ov,
                                const float* scale1, const float* gamma1, const float* beta1, float* running_mean1,
                                float* running_var1, const float* gamma2, const float* beta2, float* running_mean2,
-                               float* running_var2, int training, float eps, float momentum, float* coef, void* stream);
+                               float* running_var2, int training, float eps, float momentum, float* coef,
+                               int64_t* num_batches_tracked1, int64_t* num_batches_tracked2 /* += 1 when training; may be NULL */,
+                               void* stream);
 /* s_out[P,Os] = leaky_relu(A1*(A1>=0 ? n_max : n_min) + B1);  v_out[P,3,Ov] = gate[b]*(Av*mv + Bv*mvn).          */
 int svnet_edgeblock_apply_f32(const int32_t* n_max, const int32_t* n_min, const float* mv, const float* mvn,
                               const float* coef, const float* gate, int64_t P, int64_t N, int64_t Os, int64_t Ov,
@@ -185,6 +191,17 @@ int svnet_edgeblock_bwd_coeffs_f32(const float* red, const float* redv, const fl
                                    const float* gamma2, int64_t E, int64_t Os, int64_t Ov, int training, float* bcoef,
                                    float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, void* stream);
 int svnet_edgeblock_bwd_f32(const svnet_edgeblock_bwd_desc* desc, void* stream);
+/* After the edge pass: acat [3P, 2Ov+6] = [du_acc - dvc | dvc | dzp_acc - dzc | dzc] (the gradient of [U|T|Zp|Zq], so that
+ * dv += (acat*scv) . wv and GXc = acat^T . v), and dbeta1 [2Cs+6Cv] = dbeta_perm in the reference's feature order.     */
+int svnet_edgeblock_bwd_mid_f32(const float* du_acc, const float* dvc, const float* dzp_acc, const float* dzc, int64_t P,
+                                int64_t Ov, float* acat, const float* dbeta_perm, int64_t Cs, int64_t Cv, float* dbeta1,
+                                void* stream);
+/* STE chain rule (svnet_binweight_grad_f32's formula, ASSIGNED) for linear1 from GXp [Os,320] (fused column order), for
+ * linear2 from GXc[0:2Ov] and for the v2s frame from GXc[2Ov:2Ov+6]  (GXc [2Ov+6, Cv]).                              */
+int svnet_edgeblock_bwd_params_f32(const float* GXp, const float* GXc, const float* W1, const float* scale1, const float* W2,
+                                   const float* scale2, const float* Wz, const float* scalez, int64_t Os, int64_t Ov,
+                                   int64_t Cs, int64_t Cv, float* dW1, float* dscale1, float* dW2, float* dscale2, float* dWz,
+                                   float* dscalez, void* stream);
 
 /* ------------------------------------------------------------------ fused FIRST edge layer (full precision)
  * get_graph_feature (sv_util.py:28-62) -> Vector2Scalar(2,3) (init_scalar, sv_layers.py:111-129)
@@ -206,7 +223,8 @@ int svnet_xyzblock_fwd_f32(const svnet_xyzblock_desc* desc, void* stream);
 int svnet_xyzblock_coeffs_f32(const double* stat_y, const double* stat_v, int64_t E, int64_t Os, int64_t Ov,
                               const float* gamma1, const float* beta1, float* running_mean1, float* running_var1,
                               const float* gamma2, const float* beta2, float* running_mean2, float* running_var2,
-                              int training, float eps, float momentum, float* coef, void* stream);
+                              int training, float eps, float momentum, float* coef, int64_t* num_batches_tracked1,
+                              int64_t* num_batches_tracked2, void* stream);
 int svnet_xyzblock_apply_f32(const float* y_max, const float* y_min, const float* mv, const float* mvn, const float* coef,
                              const float* gate, int64_t P, int64_t N, int64_t Os, int64_t Ov, float slope, float* s_out,
                              float* v_out, void* stream);
@@ -242,9 +260,10 @@ int svnet_v2s_bwd_f32(const float* v, const float* w_eff, const float* ds, const
  * stats: sums[0:C] = sum_m x, sums[C:2C] = sum_m x^2 in fp64 (caller zero-fills).
  * kind 0: x is [M,C];  kind 1: x is [M,3,C] and the statistic is n = ||x[m,:,c]||_2 + 1e-6 (VectorBN, :94). */
 int svnet_colstats_f64(const float* x, int64_t M, int64_t C, int kind, double* sums, void* stream);
-/* mean/invstd from the sums (training) and running-stat update (running_* may be NULL).            */
+/* mean/invstd from the sums (training), running-stat update and num_batches_tracked += 1 (each may be NULL). */
 int svnet_bn_finalize_f32(const double* sums, int64_t M, int64_t C, float eps, float momentum, float* mean,
-                          float* invstd, float* running_mean, float* running_var, void* stream);
+                          float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                          void* stream);
 /* eval mode: mean = running_mean, invstd = 1/sqrt(running_var+eps).                                 */
 int svnet_bn_eval_stats_f32(const float* running_mean, const float* running_var, int64_t C, float eps, float* mean,
                             float* invstd, void* stream);
@@ -286,6 +305,15 @@ int svnet_pool_bwd_f32(const float* g, const int32_t* argmax, int64_t outer, int
  * kind 1 = relu, 2 = sigmoid, 3 = leaky-relu(0.2).  Backward uses the OUTPUT y.                      */
 int svnet_act_fwd_f32(const float* x, int64_t n, int kind, float* y, void* stream);
 int svnet_act_bwd_f32(const float* g, const float* y, int64_t n, int kind, float* dx, void* stream);
+
+/* ------------------------------------------------------------------ gate MLP of an SVBlock (sv_layers.py:156-161,179-183)
+ * gate[b,:] = sigmoid(W2 . relu(W0 . (in_scale*gin[b,:])));  W0 [H,Cin], W2 [Ov,H], no biases; h [B,H] is saved for the
+ * backward.  Backward: dgin = out_scale * dL/d(in_scale*gin) (may be NULL), dW0 / dW2 ACCUMULATE (float atomics).       */
+int svnet_gate_mlp_fwd_f32(const float* gin, float in_scale, const float* W0, const float* W2, int64_t B, int64_t Cin,
+                           int64_t H, int64_t Ov, float* h, float* gate, void* stream);
+int svnet_gate_mlp_bwd_f32(const float* dgate, const float* gate, const float* h, const float* gin, float in_scale,
+                           const float* W0, const float* W2, int64_t B, int64_t Cin, int64_t H, int64_t Ov, float out_scale,
+                           float* dgin, float* dW0, float* dW2, void* stream);
 
 /* ------------------------------------------------------------------ label-smoothed cross entropy (utils.py:33-50 cal_loss)
  * logits [R,C], target [R] int64; loss = mean_r -(soft . log_softmax); dlogits = d loss / d logits.   */

@@ -107,24 +107,27 @@ SIGNATURES = {
     "svnet_gemm_f32": (c_int, [ctypes.POINTER(GemmDesc), c_p]),
     "svnet_binweight_prepare_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),
     "svnet_binlinear_fwd_f32": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),
-    "svnet_binweight_grad_f32": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p]),
+    "svnet_binweight_grad_f32": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_int, c_p]),
+    "svnet_edgeblock_prepare_vec_f32": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p]),
+    "svnet_edgeblock_bwd_mid_f32": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_p, c_p]),
+    "svnet_edgeblock_bwd_params_f32": (c_int, [c_p] * 8 + [c_i64] * 4 + [c_p] * 6 + [c_p]),
     "svnet_edgeblock_prepare_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p]),
     "svnet_edgeblock_fwd_f32": (c_int, [ctypes.POINTER(EdgeBlockDesc), c_p]),
-    "svnet_edgeblock_coeffs_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_f, c_f, c_p, c_p]),
+    "svnet_edgeblock_coeffs_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_f, c_f, c_p, c_p, c_p, c_p]),
     "svnet_edgeblock_apply_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p]),
     "svnet_edgeblock_wbt_bf16": (c_int, [c_p, c_p, c_i64, c_p, c_p]),
     "svnet_edgeblock_bwd_prelude_f32": (c_int, [c_p] * 9 + [c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p, c_p, c_p]),
     "svnet_edgeblock_bwd_coeffs_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_p]),
     "svnet_edgeblock_bwd_f32": (c_int, [ctypes.POINTER(EdgeBlockBwdDesc), c_p]),
     "svnet_xyzblock_fwd_f32": (c_int, [ctypes.POINTER(XyzBlockDesc), c_p]),
-    "svnet_xyzblock_coeffs_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_f, c_f, c_p, c_p]),
+    "svnet_xyzblock_coeffs_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_f, c_f, c_p, c_p, c_p, c_p]),
     "svnet_xyzblock_apply_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p]),
     "svnet_xyzblock_bwd_prelude_f32": (c_int, [c_p] * 8 + [c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p, c_p, c_p]),
     "svnet_xyzblock_bwd_f32": (c_int, [ctypes.POINTER(XyzBlockBwdDesc), c_p]),
     "svnet_v2s_fwd_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "svnet_v2s_bwd_f32": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "svnet_colstats_f64": (c_int, [c_p, c_i64, c_i64, c_int, c_p, c_p]),
-    "svnet_bn_finalize_f32": (c_int, [c_p, c_i64, c_i64, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
+    "svnet_bn_finalize_f32": (c_int, [c_p, c_i64, c_i64, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p]),
     "svnet_bn_eval_stats_f32": (c_int, [c_p, c_p, c_i64, c_f, c_p, c_p, c_p]),
     "svnet_bn_act_fwd_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_int, c_f, c_p, c_p]),
     "svnet_bn_act_bwd_reduce_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_int, c_f, c_p, c_p]),
@@ -136,6 +139,8 @@ SIGNATURES = {
     "svnet_pool_bwd_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_int, c_p, c_p]),
     "svnet_act_fwd_f32": (c_int, [c_p, c_i64, c_int, c_p, c_p]),
     "svnet_act_bwd_f32": (c_int, [c_p, c_p, c_i64, c_int, c_p, c_p]),
+    "svnet_gate_mlp_fwd_f32": (c_int, [c_p, c_f, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
+    "svnet_gate_mlp_bwd_f32": (c_int, [c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p, c_p]),
     "svnet_smooth_ce_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_f, c_p, c_p, c_p]),
 }
 

@@ -157,6 +157,30 @@ class FpLinear(torch.autograd.Function):
         return dx, dW, db
 
 
+def _binweight_grad(GX, W, sc, O, K, training):
+    """STE chain rule to (W, scale) of a bw layer; eval mode binarizes with a bare sign(): no gradient reaches W
+    (sv_layers.py:44-45)."""
+    dev = GX.device
+    dsc = torch.empty((O,), dtype=torch.float32, device=dev)
+    dW = torch.empty((O, K), dtype=torch.float32, device=dev) if training else torch.zeros((O, K), dtype=torch.float32, device=dev)
+    call("svnet_binweight_grad_f32", _p(GX), _p(W), _p(sc), O, K, _p(dW) if training else None, _p(dsc), 0, _stream())
+    return dW, dsc
+
+
+def _zeros_pool(dev, *specs):
+    """One zero-filled allocation (one fill launch) carved into tensors: specs are (shape, dtype) pairs."""
+    offs, total = [], 0
+    for shape, dtype in specs:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        offs.append((total, nbytes))
+        total += (nbytes + 255) // 256 * 256
+    buf = torch.zeros((max(total, 1),), dtype=torch.uint8, device=dev)
+    return [buf[o:o + nb].view(dtype).view(shape) for (o, nb), (shape, dtype) in zip(offs, specs)]
+
+
 class BwLinear(torch.autograd.Function):
     """y = (x sign(W)^T) * scale with fp32 activations (sv_layers.py:44-49 with bw only: linear2, v2s.linear, svfuse)."""
 
@@ -191,10 +215,7 @@ class BwLinear(torch.autograd.Function):
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             GX = torch.empty((O, K), dtype=torch.float32, device=g.device)
             gemm(O, K, M, A=g2, a_rs=1, a_cs=O, B=x2, b_rs=K, b_cs=1, C=GX, ldc=K)
-            dW = torch.zeros((O, K), dtype=torch.float32, device=g.device)
-            dsc = torch.zeros((O,), dtype=torch.float32, device=g.device)
-            # eval mode binarizes with a bare sign(): no straight-through gradient reaches W (sv_layers.py:44-45)
-            call("svnet_binweight_grad_f32", _p(GX), _p(W), _p(sc), O, K, _p(dW) if ctx.training else None, _p(dsc), _stream())
+            dW, dsc = _binweight_grad(GX, W, sc, O, K, ctx.training)
             dsc = dsc.view(ctx.sshape)
         return dx, dW, dsc, None
 
@@ -249,9 +270,7 @@ class BinLinear(torch.autograd.Function):
             # GX[o,k] = sum_m g[m,o] x_b[m,k], computed as (x_b^T g)[k,o] with the ternary operand on the A side
             GX = torch.empty((O, K), dtype=torch.float32, device=dev)
             gemm(K, O, M, a_planes=(x_sign, x_nz), B=g2, b_rs=O, b_cs=1, C=GX, ldc=1, c_cs=K)
-            dW = torch.zeros((O, K), dtype=torch.float32, device=dev)
-            dsc = torch.zeros((O,), dtype=torch.float32, device=dev)
-            call("svnet_binweight_grad_f32", _p(GX), _p(W), _p(sc), O, K, _p(dW) if ctx.training else None, _p(dsc), _stream())
+            dW, dsc = _binweight_grad(GX, W, sc, O, K, ctx.training)
             dsc = dsc.view(sshape)
         if has_bias and ctx.needs_input_grad[4]:
             dbias = pool_raw(g2, 1, M, O, 1)[0].view(O) * float(M)
@@ -301,16 +320,14 @@ class V2S(torch.autograd.Function):
         call("svnet_v2s_bwd_f32", _p(v3), _p(w_eff), _p(gs2), _p(gz2), M, C, J, _p(dv), _p(GX), _stream())
         dW, dsc = GX, None
         if sc is not None:
-            dW = torch.zeros((J, C), dtype=torch.float32, device=v3.device)
-            dsc = torch.zeros((J,), dtype=torch.float32, device=v3.device)
-            call("svnet_binweight_grad_f32", _p(GX), _p(W), _p(sc), J, C, _p(dW) if ctx.training else None, _p(dsc), _stream())
+            dW, dsc = _binweight_grad(GX, W, sc, J, C, ctx.training)
             dsc = dsc.view(ctx.sshape)
         return dv.view(ctx.vshape), dW, dsc, None
 
 
 # ----------------------------------------------------------------------------- normalisation
 
-def _batch_stats(x, M, C, kind, running_mean, running_var, training, momentum, eps):
+def _batch_stats(x, M, C, kind, running_mean, running_var, training, momentum, eps, nbt=None):
     L = _lib.lib()
     dev = x.device
     mean = torch.empty((C,), dtype=torch.float32, device=dev)
@@ -319,7 +336,7 @@ def _batch_stats(x, M, C, kind, running_mean, running_var, training, momentum, e
         sums = torch.zeros((2 * C,), dtype=torch.float64, device=dev)
         call("svnet_colstats_f64", _p(x), M, C, kind, _p(sums), _stream())
         call("svnet_bn_finalize_f32", _p(sums), M, C, eps, momentum, _p(mean), _p(invstd), _p(running_mean), _p(running_var),
-                                      _stream())
+                                      _p(nbt), _stream())
     else:
         call("svnet_bn_eval_stats_f32", _p(running_mean), _p(running_var), C, eps, _p(mean), _p(invstd), _stream())
     return mean, invstd
@@ -329,11 +346,11 @@ class BNAct(torch.autograd.Function):
     """BatchNorm1d over rows (+ LeakyReLU / ReLU): sv_layers.py:189-190, sv_dgcnn_cls.py:76-78."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, act, slope):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, act, slope, nbt=None):
         _hip(x, gamma, beta)
         x2 = _f32c(x).reshape(-1, x.shape[-1])
         M, C = x2.shape
-        mean, invstd = _batch_stats(x2, M, C, 0, running_mean, running_var, training, BN_MOMENTUM, BN_EPS)
+        mean, invstd = _batch_stats(x2, M, C, 0, running_mean, running_var, training, BN_MOMENTUM, BN_EPS, nbt)
         y = torch.empty_like(x2)
         call("svnet_bn_act_fwd_f32", _p(x2), _p(mean), _p(invstd), _p(gamma), _p(beta), M, C, act, slope, _p(y), _stream())
         ctx.save_for_backward(x2, mean, invstd, gamma, beta)
@@ -355,18 +372,18 @@ class BNAct(torch.autograd.Function):
             call("svnet_bn_act_bwd_apply_f32", _p(g2), _p(x2), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(red), M, C, act, slope,
                                                int(training), _p(dx), _stream())
             dx = dx.view(xshape)
-        return dx, red[C:], red[:C], None, None, None, None, None
+        return dx, red[C:], red[:C], None, None, None, None, None, None
 
 
 class VBN(torch.autograd.Function):
     """VectorBN (+ gate): out = v * BN(|v|+eps) / (|v|+eps) * gate   (sv_layers.py:86-102, :194)."""
 
     @staticmethod
-    def forward(ctx, v, gamma, beta, running_mean, running_var, gate, rows_per_batch, training):
+    def forward(ctx, v, gamma, beta, running_mean, running_var, gate, rows_per_batch, training, nbt=None):
         _hip(v, gamma, beta, gate)
         v3 = _f32c(v).reshape(-1, 3, v.shape[-1])
         M, _, C = v3.shape
-        mean, invstd = _batch_stats(v3, M, C, 1, running_mean, running_var, training, BN_MOMENTUM, BN_EPS)
+        mean, invstd = _batch_stats(v3, M, C, 1, running_mean, running_var, training, BN_MOMENTUM, BN_EPS, nbt)
         gate2 = None if gate is None else _f32c(gate).reshape(-1, C)
         out = torch.empty_like(v3)
         call("svnet_vbn_fwd_f32", _p(v3), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(gate2), rows_per_batch, M, C, _p(out),
@@ -381,8 +398,10 @@ class VBN(torch.autograd.Function):
         M, C, rpb, training, vshape, gshape = ctx.meta
         L = _lib.lib()
         g3 = _f32c(g).reshape(M, 3, C)
-        red = torch.zeros((2 * C,), dtype=torch.float32, device=g.device)
-        dgate = None if gate2 is None else torch.zeros_like(gate2)
+        if gate2 is None:
+            red, dgate = torch.zeros((2 * C,), dtype=torch.float32, device=g.device), None
+        else:
+            red, dgate = _zeros_pool(g.device, ((2 * C,), torch.float32), (tuple(gate2.shape), torch.float32))
         call("svnet_vbn_bwd_reduce_f32", _p(g3), _p(v3), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(gate2), rpb, M, C, _p(red),
                                          _p(dgate), _stream())
         dv = None
@@ -393,7 +412,7 @@ class VBN(torch.autograd.Function):
             dv = dv.view(vshape)
         if dgate is not None:
             dgate = dgate.view(gshape)
-        return dv, red[C:], red[:C], None, None, dgate, None, None
+        return dv, red[C:], red[:C], None, None, dgate, None, None, None
 
 
 # ----------------------------------------------------------------------------- pooling / activations / loss
@@ -402,7 +421,7 @@ def pool_raw(x, outer, R, inner, mode):
     """x contiguous viewed as [outer,R,inner] -> (out [outer,inner], argmax int32 or None)."""
     out = torch.empty((outer, inner), dtype=torch.float32, device=x.device)
     arg = torch.empty((outer, inner), dtype=torch.int32, device=x.device) if mode == 0 else None
-    ws = torch.empty((outer * inner,), dtype=torch.int64, device=x.device) if (mode == 0 and R >= 256 and outer * inner < 65536) else None
+    ws = torch.empty((outer * inner,), dtype=torch.int64, device=x.device) if (mode == 0 and R >= 256 and outer * inner < (1 << 20)) else None
     call("svnet_pool_fwd_f32", _p(x), outer, R, inner, mode, _p(out), _p(arg), _p(ws), 0 if ws is None else ws.numel() * 8, _stream())
     return out, arg
 
@@ -460,6 +479,34 @@ class Act(torch.autograd.Function):
         return dx, None
 
 
+class GateMLP(torch.autograd.Function):
+    """gate = sigmoid(W2 . relu(W0 . pooled)) of an SVBlock (sv_layers.py:156-161,179-183), one launch each way."""
+
+    @staticmethod
+    def forward(ctx, pooled, W0, W2):
+        pooled, W0c, W2c = _f32c(pooled), _f32c(W0), _f32c(W2)
+        B, Cin = pooled.shape
+        H, Ov = W0c.shape[0], W2c.shape[0]
+        h = torch.empty((B, H), device=pooled.device, dtype=torch.float32)
+        gate = torch.empty((B, Ov), device=pooled.device, dtype=torch.float32)
+        call("svnet_gate_mlp_fwd_f32", _p(pooled), 1.0, _p(W0c), _p(W2c), B, Cin, H, Ov, _p(h), _p(gate), _stream())
+        ctx.save_for_backward(pooled, W0c, W2c, h, gate)
+        return gate
+
+    @staticmethod
+    def backward(ctx, dgate):
+        pooled, W0, W2, h, gate = ctx.saved_tensors
+        dgate = _f32c(dgate)
+        B, Cin = pooled.shape
+        H, Ov = W0.shape[0], W2.shape[0]
+        zb = torch.zeros((H * Cin + Ov * H,), device=pooled.device, dtype=torch.float32)
+        dW0, dW2 = zb[:H * Cin].view(H, Cin), zb[H * Cin:].view(Ov, H)
+        dpooled = torch.empty_like(pooled) if ctx.needs_input_grad[0] else None
+        call("svnet_gate_mlp_bwd_f32", _p(dgate), _p(gate), _p(h), _p(pooled), 1.0, _p(W0), _p(W2), B, Cin, H, Ov, 1.0,
+             _p(dpooled) if dpooled is not None else None, _p(dW0), _p(dW2), _stream())
+        return dpooled, dW0, dW2
+
+
 class SmoothCE(torch.autograd.Function):
     """Label-smoothed cross entropy, mean over rows (utils.py:33-50 cal_loss)."""
 
@@ -494,7 +541,8 @@ class EdgeBlock(torch.autograd.Function):
     (csrc/edgeblock.hip).  Inputs are the POINT tables; no edge tensor is materialised in either direction."""
 
     @staticmethod
-    def forward(ctx, s, v, idx, k, training, Wz, scz, W1, beta1, scale1, g1, b1, rm1, rv1, W2, sc2, g2, b2, rm2, rv2, Wg0, Wg2):
+    def forward(ctx, s, v, idx, k, training, Wz, scz, W1, beta1, scale1, g1, b1, rm1, rv1, W2, sc2, g2, b2, rm2, rv2, Wg0, Wg2,
+                nbt1=None, nbt2=None):
         _hip(s, v, idx)
         from ._lib import EdgeBlockDesc
         s = _f32c(s)
@@ -506,25 +554,22 @@ class EdgeBlock(torch.autograd.Function):
         dev = s.device
         f32 = dict(dtype=torch.float32, device=dev)
         idx = idx.contiguous()
+        W1c, W2c, Wzc, Wg0c, Wg2c = _f32c(W1), _f32c(W2), _f32c(Wz), _f32c(Wg0), _f32c(Wg2)
+        sc1, sc2f, sczf = _f32c(scale1).reshape(-1), _f32c(sc2).reshape(-1), _f32c(scz).reshape(-1)
 
-        # per-point pieces of the two linear maps on v_e = [v_j - v_i, v_i]
-        wz_b = torch.empty((3, 2 * Cv), **f32)
-        w2_b = torch.empty((Ov, 2 * Cv), **f32)
-        call("svnet_binweight_prepare_f32", _p(_f32c(Wz)), None, 3, 2 * Cv, None, None, _p(wz_b), None, _stream())
-        call("svnet_binweight_prepare_f32", _p(_f32c(W2)), None, Ov, 2 * Cv, None, None, _p(w2_b), None, _stream())
-        wzz = torch.cat((wz_b[:, :Cv], wz_b[:, Cv:]), dim=0).contiguous()            # [6,Cv]
-        w2c = torch.cat((w2_b[:, :Cv], w2_b[:, Cv:]), dim=0).contiguous()            # [2Ov,Cv]
-        scz2 = torch.cat((scz.reshape(-1), scz.reshape(-1)))
-        sc22 = torch.cat((sc2.reshape(-1), sc2.reshape(-1)))
+        # per-point pieces of the two linear maps on v_e = [v_j - v_i, v_i]: ut = [U | T], zz = [Zp | Zq]
+        wv = torch.empty((2 * Ov + 6, Cv), **f32)
+        scv = torch.empty((2 * Ov + 6,), **f32)
+        call("svnet_edgeblock_prepare_vec_f32", _p(W2c), _p(sc2f), _p(Wzc), _p(sczf), Ov, Cv, _p(wv), _p(scv), _stream())
         zz = torch.empty((P * 3, 6), **f32)
         ut = torch.empty((P * 3, 2 * Ov), **f32)
-        gemm(3 * P, 6, Cv, A=v, a_rs=Cv, a_cs=1, B=wzz, b_rs=1, b_cs=Cv, b_exact=True, C=zz, ldc=6, col_scale=scz2)
-        gemm(3 * P, 2 * Ov, Cv, A=v, a_rs=Cv, a_cs=1, B=w2c, b_rs=1, b_cs=Cv, b_exact=True, C=ut, ldc=2 * Ov, col_scale=sc22)
+        gemm(3 * P, 6, Cv, A=v, a_rs=Cv, a_cs=1, B=wv[2 * Ov:], b_rs=1, b_cs=Cv, b_exact=True, C=zz, ldc=6, col_scale=scv[2 * Ov:])
+        gemm(3 * P, 2 * Ov, Cv, A=v, a_rs=Cv, a_cs=1, B=wv, b_rs=1, b_cs=Cv, b_exact=True, C=ut, ldc=2 * Ov, col_scale=scv)
 
         w_sign = torch.empty((Os, 5), dtype=torch.int64, device=dev)
         w_nz = torch.empty((Os, 5), dtype=torch.int64, device=dev)
         beta_perm = torch.empty((5 * 64,), **f32)
-        call("svnet_edgeblock_prepare_f32", _p(_f32c(W1)), _p(_f32c(beta1)), Os, Cs, Cv, _p(w_sign), _p(w_nz), _p(beta_perm), _stream())
+        call("svnet_edgeblock_prepare_f32", _p(W1c), _p(_f32c(beta1)), Os, Cs, Cv, _p(w_sign), _p(w_nz), _p(beta_perm), _stream())
 
         n_max = torch.empty((P, Os), dtype=torch.int32, device=dev)
         n_min = torch.empty((P, Os), dtype=torch.int32, device=dev)
@@ -532,9 +577,11 @@ class EdgeBlock(torch.autograd.Function):
         slot_min = torch.empty((P, Os), dtype=torch.uint8, device=dev)
         mv = torch.empty((P, 3, Ov), **f32)
         mvn = torch.empty((P, 3, Ov), **f32)
-        stat_n = torch.zeros((2 * Os,), dtype=torch.int64, device=dev) if training else None
-        stat_v = torch.zeros((2 * Ov,), dtype=torch.float64, device=dev) if training else None
-        gate_sum = torch.zeros((B, 2 * Cs), **f32)
+        if training:
+            stat_n, stat_v, gate_sum = _zeros_pool(dev, ((2 * Os,), torch.int64), ((2 * Ov,), torch.float64), ((B, 2 * Cs), torch.float32))
+        else:
+            stat_n = stat_v = None
+            gate_sum = torch.zeros((B, 2 * Cs), **f32)
         d = EdgeBlockDesc()
         d.B, d.N, d.k = B, N, k
         d.Cs, d.Cv, d.Os, d.Ov = Cs, Cv, Os, Ov
@@ -544,46 +591,46 @@ class EdgeBlock(torch.autograd.Function):
         d.mv, d.mvn, d.stat_n, d.stat_v, d.gate_sum = _p(mv), _p(mvn), _p(stat_n), _p(stat_v), _p(gate_sum)
         call("svnet_edgeblock_fwd_f32", ctypes.byref(d), _stream())
 
-        # gate MLP on the mean edge scalar (sv_layers.py:156-161,179-183): tiny [B,.] products
-        gin = gate_sum * (1.0 / float(N * k))
+        # gate MLP on the mean edge scalar (sv_layers.py:156-161,179-183): one workgroup per cloud
         H = Wg0.shape[0]
-        hpre = torch.empty((B, H), **f32)
-        gemm(B, H, 2 * Cs, A=gin, a_rs=2 * Cs, a_cs=1, B=_f32c(Wg0), b_rs=1, b_cs=2 * Cs, C=hpre, ldc=H)
-        h = _act_raw(hpre, 1)
-        gpre = torch.empty((B, Ov), **f32)
-        gemm(B, Ov, H, A=h, a_rs=H, a_cs=1, B=_f32c(Wg2), b_rs=1, b_cs=H, C=gpre, ldc=Ov)
-        gate = _act_raw(gpre, 2)
+        h = torch.empty((B, H), **f32)
+        gate = torch.empty((B, Ov), **f32)
+        call("svnet_gate_mlp_fwd_f32", _p(gate_sum), 1.0 / float(N * k), _p(Wg0c), _p(Wg2c), B, 2 * Cs, H, Ov, _p(h), _p(gate), _stream())
 
         coef = torch.empty((4 * Os + 4 * Ov,), **f32)
-        call("svnet_edgeblock_coeffs_f32", _p(stat_n), _p(stat_v), E, Os, Ov, _p(scale1.reshape(-1)), _p(g1), _p(b1), _p(rm1), _p(rv1),
-             _p(g2), _p(b2), _p(rm2), _p(rv2), int(training), BN_EPS, BN_MOMENTUM, _p(coef), _stream())
+        call("svnet_edgeblock_coeffs_f32", _p(stat_n), _p(stat_v), E, Os, Ov, _p(sc1), _p(g1), _p(b1), _p(rm1), _p(rv1),
+             _p(g2), _p(b2), _p(rm2), _p(rv2), int(training), BN_EPS, BN_MOMENTUM, _p(coef), _p(nbt1), _p(nbt2), _stream())
         s_out = torch.empty((B, N, Os), **f32)
         v_out = torch.empty((B, N, 3, Ov), **f32)
         call("svnet_edgeblock_apply_f32", _p(n_max), _p(n_min), _p(mv), _p(mvn), _p(coef), _p(gate), P, N, Os, Ov, 0.2, _p(s_out),
              _p(v_out), _stream())
         ctx.save_for_backward(s, v, idx, zz, ut, w_sign, w_nz, beta_perm, n_max, n_min, slot_max, slot_min, mv, mvn, coef, gate, h,
-                              gin, wzz, w2c, scz2, sc22, W1, scale1, W2, sc2, Wz, scz, g1, g2, Wg0, Wg2)
-        ctx.meta = (B, N, k, Cs, Cv, Os, Ov, bool(training))
+                              gate_sum, wv, scv, W1c, sc1, W2c, sc2f, Wzc, sczf, g1, g2, Wg0c, Wg2c)
+        ctx.meta = (B, N, k, Cs, Cv, Os, Ov, bool(training), scale1.shape, sc2.shape, scz.shape)
         return s_out, v_out
 
     @staticmethod
     def backward(ctx, gs, gv):
         from ._lib import EdgeBlockBwdDesc
-        (s, v, idx, zz, ut, w_sign, w_nz, beta_perm, n_max, n_min, slot_max, slot_min, mv, mvn, coef, gate, h, gin, wzz, w2c,
-         scz2, sc22, W1, scale1, W2, sc2, Wz, scz, g1, g2, Wg0, Wg2) = ctx.saved_tensors
-        B, N, k, Cs, Cv, Os, Ov, training = ctx.meta
+        (s, v, idx, zz, ut, w_sign, w_nz, beta_perm, n_max, n_min, slot_max, slot_min, mv, mvn, coef, gate, h, gin, wv, scv,
+         W1, sc1, W2, sc2, Wz, scz, g1, g2, Wg0, Wg2) = ctx.saved_tensors
+        B, N, k, Cs, Cv, Os, Ov, training, sh1, sh2, shz = ctx.meta
         P, E = B * N, B * N * k
         dev = s.device
         f32 = dict(dtype=torch.float32, device=dev)
+        F = torch.float32
         gs = _f32c(gs).reshape(P, Os)
         gv = _f32c(gv).reshape(P, 3, Ov)
-        sc1 = scale1.reshape(-1)
+        H = Wg0.shape[0]
+        K1, R = 2 * Cs + 6 * Cv, 2 * Ov + 6
+
+        # every accumulator of this backward from ONE zero fill
+        (red, redv, dgate, dWg0, dWg2, ds_acc, dv_acc, du_acc, dvc, dzp_acc, dzc, dbeta_perm, GXp, GXc) = _zeros_pool(
+            dev, ((2 * Os,), F), ((2 * Ov,), F), ((B, Ov), F), ((H, 2 * Cs), F), ((Ov, H), F), ((P, Cs), F), ((P, 3, Cv), F),
+            ((P, 3, Ov), F), ((P, 3, Ov), F), ((P, 3, 3), F), ((P, 3, 3), F), ((320,), F), ((Os, 320), F), ((R, Cv), F))
 
         # ---- point-level prelude: BatchNorm reductions, gate gradient
         gy = torch.empty((P, Os), **f32)
-        red = torch.zeros((2 * Os,), **f32)
-        redv = torch.zeros((2 * Ov,), **f32)
-        dgate = torch.zeros((B, Ov), **f32)
         call("svnet_edgeblock_bwd_prelude_f32", _p(gs), _p(gv), _p(n_max), _p(n_min), _p(mv), _p(mvn), _p(coef), _p(sc1), _p(gate),
              P, N, Os, Ov, 0.2, _p(gy), _p(red), _p(redv), _p(dgate), _stream())
         bcoef = torch.empty((3 * Os + 2 * Ov,), **f32)
@@ -592,20 +639,11 @@ class EdgeBlock(torch.autograd.Function):
         call("svnet_edgeblock_bwd_coeffs_f32", _p(red), _p(redv), _p(coef), _p(g1), _p(g2), E, Os, Ov, int(training), _p(bcoef), _p(dg1),
              _p(db1), _p(dg2), _p(db2), _stream())
 
-        # ---- gate MLP backward (tiny [B,.] products)
-        H = Wg0.shape[0]
-        dgpre = torch.empty_like(dgate)
-        call("svnet_act_bwd_f32", _p(dgate), _p(gate), dgate.numel(), 2, _p(dgpre), _stream())
-        dWg2 = torch.empty((Ov, H), **f32)
-        gemm(Ov, H, B, A=dgpre, a_rs=1, a_cs=Ov, B=h, b_rs=H, b_cs=1, C=dWg2, ldc=H)
-        dh = torch.empty((B, H), **f32)
-        gemm(B, H, Ov, A=dgpre, a_rs=Ov, a_cs=1, B=_f32c(Wg2), b_rs=H, b_cs=1, C=dh, ldc=H)
-        dhpre = torch.empty_like(dh)
-        call("svnet_act_bwd_f32", _p(dh), _p(h), dh.numel(), 1, _p(dhpre), _stream())
-        dWg0 = torch.empty((H, 2 * Cs), **f32)
-        gemm(H, 2 * Cs, B, A=dhpre, a_rs=1, a_cs=H, B=gin, b_rs=2 * Cs, b_cs=1, C=dWg0, ldc=2 * Cs)
+        # ---- gate MLP backward: dW0, dW2 and the per-edge constant of the gate path, one workgroup per cloud
         gconst = torch.empty((B, 2 * Cs), **f32)
-        gemm(B, 2 * Cs, H, A=dhpre, a_rs=H, a_cs=1, B=_f32c(Wg0), b_rs=2 * Cs, b_cs=1, C=gconst, ldc=2 * Cs, alpha=1.0 / float(N * k))
+        inv_nk = 1.0 / float(N * k)
+        call("svnet_gate_mlp_bwd_f32", _p(dgate), _p(gate), _p(h), _p(gin), inv_nk, _p(Wg0), _p(Wg2), B, 2 * Cs, H, Ov,
+             inv_nk, _p(gconst), _p(dWg0), _p(dWg2), _stream())
 
         # ---- the edge pass
         wbt = torch.empty((320 * Os,), dtype=torch.int16, device=dev)
@@ -613,13 +651,6 @@ class EdgeBlock(torch.autograd.Function):
         dn_out = torch.empty((E, Os), **f32)
         x_sign = torch.empty(((E + 63) // 64, 320), dtype=torch.int64, device=dev)
         x_nz = torch.empty(((E + 63) // 64, 320), dtype=torch.int64, device=dev)
-        ds_acc = torch.zeros((P, Cs), **f32)
-        dv_acc = torch.zeros((P, 3, Cv), **f32)
-        du_acc = torch.zeros((P, 3, Ov), **f32)
-        dvc = torch.zeros((P, 3, Ov), **f32)
-        dzp_acc = torch.zeros((P, 3, 3), **f32)
-        dzc = torch.zeros((P, 3, 3), **f32)
-        dbeta_perm = torch.zeros((320,), **f32)
         d = EdgeBlockBwdDesc()
         d.B, d.N, d.k = B, N, k
         d.Cs, d.Cv, d.Os, d.Ov = Cs, Cv, Os, Ov
@@ -633,39 +664,24 @@ class EdgeBlock(torch.autograd.Function):
         d.debug = _p(DEBUG_BUFFER)
         call("svnet_edgeblock_bwd_f32", ctypes.byref(d), _stream())
 
-        # ---- linear1 parameters: GX = dy^T . x_b (MFMA, ternary planes), back to the reference's column order
-        perm = _fused_columns(Cs, Cv, dev)
-        GXp = torch.empty((Os, 320), **f32)
-        gemm(320, Os, E, a_planes=(x_sign, x_nz), B=dn_out, b_rs=Os, b_cs=1, C=GXp, ldc=1, c_cs=320)
-        GX = GXp.index_select(1, perm).contiguous()
-        dW1 = torch.zeros_like(W1)
-        dsc1 = torch.zeros((Os,), **f32)
-        call("svnet_binweight_grad_f32", _p(GX), _p(_f32c(W1)), _p(sc1), Os, 2 * Cs + 6 * Cv, _p(dW1), _p(dsc1), _stream())
-        dbeta1 = dbeta_perm.index_select(0, perm).view(1, -1)
+        # ---- gradient rows of the collapsed per-point products [U | T | Zp | Zq]; dbeta in the reference's feature order
+        acat = torch.empty((3 * P, R), **f32)
+        dbeta1 = torch.empty((1, K1), **f32)
+        call("svnet_edgeblock_bwd_mid_f32", _p(du_acc), _p(dvc), _p(dzp_acc), _p(dzc), P, Ov, _p(acat), _p(dbeta_perm), Cs, Cv,
+             _p(dbeta1), _stream())
+        # linear1: GXp = dy^T . x_b (MFMA, ternary planes, fused column order)
+        gemm(320, Os, E, a_planes=(x_sign, x_nz), B=dn_out, b_rs=Os, b_cs=1, C=GXp, ldc=1, c_cs=320, accumulate=True)
+        # linear2 and the v2s frame: dv += (acat * scv) . wv ;  GXc = acat^T . v
+        gemm(3 * P, Cv, R, A=acat, a_rs=R, a_cs=1, a_scale=scv, B=wv, b_rs=Cv, b_cs=1, b_exact=True, C=dv_acc, ldc=Cv, accumulate=True)
+        gemm(R, Cv, 3 * P, A=acat, a_rs=1, a_cs=R, B=v, b_rs=Cv, b_cs=1, C=GXc, ldc=Cv, accumulate=True)
+        dW1, dW2, dWz = torch.empty((Os, K1), **f32), torch.empty((Ov, 2 * Cv), **f32), torch.empty((3, 2 * Cv), **f32)
+        dsc1, dsc2, dscz = torch.empty((Os,), **f32), torch.empty((Ov,), **f32), torch.empty((3,), **f32)
+        call("svnet_edgeblock_bwd_params_f32", _p(GXp), _p(GXc), _p(W1), _p(sc1), _p(W2), _p(sc2), _p(Wz), _p(scz), Os, Ov, Cs, Cv,
+             _p(dW1), _p(dsc1), _p(dW2), _p(dsc2), _p(dWz), _p(dscz), _stream())
 
-        # ---- point-level backward of the collapsed linear maps (linear2: U|T, v2s frame: Zp|Zq)
-        dUT = torch.cat((du_acc - dvc, dvc), dim=-1).view(3 * P, 2 * Ov)
-        gemm(3 * P, Cv, 2 * Ov, A=dUT, a_rs=2 * Ov, a_cs=1, a_scale=sc22, B=w2c, b_rs=Cv, b_cs=1, b_exact=True, C=dv_acc, ldc=Cv,
-             accumulate=True)
-        GX2c = torch.empty((2 * Ov, Cv), **f32)
-        gemm(2 * Ov, Cv, 3 * P, A=dUT, a_rs=1, a_cs=2 * Ov, B=v, b_rs=Cv, b_cs=1, C=GX2c, ldc=Cv)
-        GX2 = torch.cat((GX2c[:Ov], GX2c[Ov:]), dim=1).contiguous()
-        dW2 = torch.zeros_like(W2)
-        dsc2 = torch.zeros((Ov,), **f32)
-        call("svnet_binweight_grad_f32", _p(GX2), _p(_f32c(W2)), _p(sc2.reshape(-1)), Ov, 2 * Cv, _p(dW2), _p(dsc2), _stream())
-
-        dZZ = torch.cat((dzp_acc - dzc, dzc), dim=-1).view(3 * P, 6)
-        gemm(3 * P, Cv, 6, A=dZZ, a_rs=6, a_cs=1, a_scale=scz2, B=wzz, b_rs=Cv, b_cs=1, C=dv_acc, ldc=Cv, accumulate=True)
-        GXzc = torch.empty((6, Cv), **f32)
-        gemm(6, Cv, 3 * P, A=dZZ, a_rs=1, a_cs=6, B=v, b_rs=Cv, b_cs=1, C=GXzc, ldc=Cv)
-        GXz = torch.cat((GXzc[:3], GXzc[3:]), dim=1).contiguous()
-        dWz = torch.zeros_like(Wz)
-        dscz = torch.zeros((3,), **f32)
-        call("svnet_binweight_grad_f32", _p(GXz), _p(_f32c(Wz)), _p(scz.reshape(-1)), 3, 2 * Cv, _p(dWz), _p(dscz), _stream())
-
-        # forward args: s, v, idx, k, training, Wz, scz, W1, beta1, scale1, g1, b1, rm1, rv1, W2, sc2, g2, b2, rm2, rv2, Wg0, Wg2
-        return (ds_acc.view(B, N, Cs), dv_acc.view(B, N, 3, Cv), None, None, None, dWz, dscz.view_as(scz), dW1, dbeta1,
-                dsc1.view_as(scale1), dg1, db1, None, None, dW2, dsc2.view_as(sc2), dg2, db2, None, None, dWg0, dWg2)
+        # forward args: s, v, idx, k, training, Wz, scz, W1, beta1, scale1, g1, b1, rm1, rv1, W2, sc2, g2, b2, rm2, rv2, Wg0, Wg2, nbt1, nbt2
+        return (ds_acc.view(B, N, Cs), dv_acc.view(B, N, 3, Cv), None, None, None, dWz, dscz.view(shz), dW1, dbeta1,
+                dsc1.view(sh1), dg1, db1, None, None, dW2, dsc2.view(sh2), dg2, db2, None, None, dWg0, dWg2, None, None)
 
 
 class XyzBlock(torch.autograd.Function):
@@ -673,7 +689,7 @@ class XyzBlock(torch.autograd.Function):
     pass over the edges (csrc/xyzblock.hip).  The coordinates receive no gradient."""
 
     @staticmethod
-    def forward(ctx, x, idx, k, training, W0, Wz, W1, g1, b1, rm1, rv1, W2, g2, b2, rm2, rv2, Wg0, Wg2):
+    def forward(ctx, x, idx, k, training, W0, Wz, W1, g1, b1, rm1, rv1, W2, g2, b2, rm2, rv2, Wg0, Wg2, nbt1=None, nbt2=None):
         _hip(x, idx)
         from ._lib import XyzBlockDesc
         x = _f32c(x.detach())
@@ -687,9 +703,11 @@ class XyzBlock(torch.autograd.Function):
         slot_max = torch.empty((P, Os), dtype=torch.uint8, device=dev)
         slot_min = torch.empty((P, Os), dtype=torch.uint8, device=dev)
         mv, mvn = torch.empty((P, 3, Ov), **f32), torch.empty((P, 3, Ov), **f32)
-        stat_y = torch.zeros((2 * Os,), dtype=torch.float64, device=dev) if training else None
-        stat_v = torch.zeros((2 * Ov,), dtype=torch.float64, device=dev) if training else None
-        gate_sum = torch.zeros((B, 6), **f32)
+        if training:
+            stat_y, stat_v, gate_sum = _zeros_pool(dev, ((2 * Os,), torch.float64), ((2 * Ov,), torch.float64), ((B, 6), torch.float32))
+        else:
+            stat_y = stat_v = None
+            gate_sum = torch.zeros((B, 6), **f32)
         W0c, Wzc, W1c, W2c = _f32c(W0), _f32c(Wz), _f32c(W1), _f32c(W2)
         d = XyzBlockDesc()
         d.B, d.N, d.k, d.Os, d.Ov = B, N, k, Os, Ov
@@ -698,18 +716,15 @@ class XyzBlock(torch.autograd.Function):
         d.stat_y, d.stat_v, d.gate_sum = _p(stat_y), _p(stat_v), _p(gate_sum)
         call("svnet_xyzblock_fwd_f32", ctypes.byref(d), _stream())
 
-        gin = gate_sum * (1.0 / float(N * k))
         H = Wg0.shape[0]
-        hpre = torch.empty((B, H), **f32)
-        gemm(B, H, 6, A=gin, a_rs=6, a_cs=1, B=_f32c(Wg0), b_rs=1, b_cs=6, C=hpre, ldc=H)
-        h = _act_raw(hpre, 1)
-        gpre = torch.empty((B, Ov), **f32)
-        gemm(B, Ov, H, A=h, a_rs=H, a_cs=1, B=_f32c(Wg2), b_rs=1, b_cs=H, C=gpre, ldc=Ov)
-        gate = _act_raw(gpre, 2)
+        h = torch.empty((B, H), **f32)
+        gate = torch.empty((B, Ov), **f32)
+        call("svnet_gate_mlp_fwd_f32", _p(gate_sum), 1.0 / float(N * k), _p(_f32c(Wg0)), _p(_f32c(Wg2)), B, 6, H, Ov, _p(h), _p(gate), _stream())
+        gin = gate_sum
 
         coef = torch.empty((4 * Os + 4 * Ov,), **f32)
         call("svnet_xyzblock_coeffs_f32", _p(stat_y), _p(stat_v), E, Os, Ov, _p(g1), _p(b1), _p(rm1), _p(rv1), _p(g2), _p(b2), _p(rm2),
-             _p(rv2), int(training), BN_EPS, BN_MOMENTUM, _p(coef), _stream())
+             _p(rv2), int(training), BN_EPS, BN_MOMENTUM, _p(coef), _p(nbt1), _p(nbt2), _stream())
         s_out = torch.empty((B, N, Os), **f32)
         v_out = torch.empty((B, N, 3, Ov), **f32)
         call("svnet_xyzblock_apply_f32", _p(y_max), _p(y_min), _p(mv), _p(mvn), _p(coef), _p(gate), P, N, Os, Ov, 0.2, _p(s_out), _p(v_out),
@@ -729,8 +744,10 @@ class XyzBlock(torch.autograd.Function):
         gs = _f32c(gs).reshape(P, Os)
         gv = _f32c(gv).reshape(P, 3, Ov)
         gy = torch.empty((P, Os), **f32)
-        red, redv = torch.zeros((2 * Os,), **f32), torch.zeros((2 * Ov,), **f32)
-        dgate = torch.zeros((B, Ov), **f32)
+        H = Wg0.shape[0]
+        F = torch.float32
+        red, redv, dgate, dWg0, dWg2, gw = _zeros_pool(dev, ((2 * Os,), F), ((2 * Ov,), F), ((B, Ov), F), ((H, 6), F), ((Ov, H), F),
+                                                       ((Os * 12 + Ov * 2 + 12,), F))
         call("svnet_xyzblock_bwd_prelude_f32", _p(gs), _p(gv), _p(y_max), _p(y_min), _p(mv), _p(mvn), _p(coef), _p(gate), P, N, Os, Ov, 0.2,
              _p(gy), _p(red), _p(redv), _p(dgate), _stream())
         bcoef = torch.empty((3 * Os + 2 * Ov,), **f32)
@@ -739,21 +756,11 @@ class XyzBlock(torch.autograd.Function):
         call("svnet_edgeblock_bwd_coeffs_f32", _p(red), _p(redv), _p(coef), _p(g1), _p(g2), E, Os, Ov, int(training), _p(bcoef), _p(dg1),
              _p(db1), _p(dg2), _p(db2), _stream())
         # gate MLP backward
-        H = Wg0.shape[0]
-        dgpre = torch.empty_like(dgate)
-        call("svnet_act_bwd_f32", _p(dgate), _p(gate), dgate.numel(), 2, _p(dgpre), _stream())
-        dWg2 = torch.empty((Ov, H), **f32)
-        gemm(Ov, H, B, A=dgpre, a_rs=1, a_cs=Ov, B=h, b_rs=H, b_cs=1, C=dWg2, ldc=H)
-        dh = torch.empty((B, H), **f32)
-        gemm(B, H, Ov, A=dgpre, a_rs=Ov, a_cs=1, B=_f32c(Wg2), b_rs=H, b_cs=1, C=dh, ldc=H)
-        dhpre = torch.empty_like(dh)
-        call("svnet_act_bwd_f32", _p(dh), _p(h), dh.numel(), 1, _p(dhpre), _stream())
-        dWg0 = torch.empty((H, 6), **f32)
-        gemm(H, 6, B, A=dhpre, a_rs=1, a_cs=H, B=gin, b_rs=6, b_cs=1, C=dWg0, ldc=6)
         gconst = torch.empty((B, 6), **f32)
-        gemm(B, 6, H, A=dhpre, a_rs=H, a_cs=1, B=_f32c(Wg0), b_rs=6, b_cs=1, C=gconst, ldc=6, alpha=1.0 / float(N * k))
+        inv_nk = 1.0 / float(N * k)
+        call("svnet_gate_mlp_bwd_f32", _p(dgate), _p(gate), _p(h), _p(gin), inv_nk, _p(_f32c(Wg0)), _p(_f32c(Wg2)), B, 6, H, Ov, inv_nk,
+             _p(gconst), _p(dWg0), _p(dWg2), _stream())
         # edge pass: parameter gradients
-        gw = torch.zeros((Os * 12 + Ov * 2 + 12,), **f32)
         d = XyzBlockBwdDesc()
         d.B, d.N, d.k, d.Os, d.Ov = B, N, k, Os, Ov
         d.x, d.idx, d.w0, d.wz, d.w1, d.w2 = _p(x), _p(idx), _p(W0), _p(Wz), _p(W1), _p(W2)
@@ -766,7 +773,7 @@ class XyzBlock(torch.autograd.Function):
         dW0 = gw[o + Ov * 2:o + Ov * 2 + 6].view(3, 2)
         dWz = gw[o + Ov * 2 + 6:].view(3, 2)
         # forward args: x, idx, k, training, W0, Wz, W1, g1, b1, rm1, rv1, W2, g2, b2, rm2, rv2, Wg0, Wg2
-        return (None, None, None, None, dW0, dWz, dW1, dg1, db1, None, None, dW2, dg2, db2, None, None, dWg0, dWg2)
+        return (None, None, None, None, dW0, dWz, dW1, dg1, db1, None, None, dW2, dg2, db2, None, None, dWg0, dWg2, None, None)
 
 
 _PERM_CACHE = {}

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void binlinear_fwd_kernel(const float* __restr
                                                             const uint64_t* __restrict__ w_sign,
                                                             const uint64_t* __restrict__ w_nz,
                                                             const float* __restrict__ scale, const float* __restrict__ bias,
-                                                            int64_t M, int K, int O, int o_base, int KW, int og_shift /*log2 threads per row group*/,
+                                                            int64_t M, int K, int O, int o_base, int o_blocks /*workgroups per row tile (small M)*/,
+                                                            int KW, int og_shift /*log2 threads per row group*/,
                                                             float* __restrict__ y, uint64_t* __restrict__ x_sign,
                                                             uint64_t* __restrict__ x_nz, uint64_t* __restrict__ x_ste) {
     extern __shared__ uint64_t lds[];  // [3][ROWS][KW]
@@ -70,6 +71,9 @@ __global__ __launch_bounds__(256) void binlinear_fwd_kernel(const float* __restr
     const int nsub = 256 >> og_shift;        // row sub-groups in phase 2
     const int o_in = tid & (OG - 1);
     const int sub = tid >> og_shift;
+    // few row tiles (the classifier head: M = batch): o_blocks workgroups share a tile, each owning OG output channels
+    const int ob = (int)(blockIdx.x % o_blocks);
+    o_base += ob * OG;
 
     // my output channels' weight words (registers for the whole kernel)
     uint64_t wsg[PPM][KWM], wnz[PPM][KWM];
@@ -89,23 +93,33 @@ __global__ __launch_bounds__(256) void binlinear_fwd_kernel(const float* __restr
     }
 
     const int64_t tiles = (M + ROWS - 1) / ROWS;
-    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    for (int64_t tile = blockIdx.x / o_blocks; tile < tiles; tile += gridDim.x / o_blocks) {
         const int64_t row0 = tile * ROWS;
         const int rows = (int)min((int64_t)ROWS, M - row0);
-        // ---- phase 1: binarize + pack. wave w handles rows w, w+4, ...
+        // ---- phase 1: binarize + pack. wave w handles rows w, w+4, ...; 4 words' loads are in flight together
         for (int r = wave; r < rows; r += 4) {
             const float* xr = x + (row0 + r) * ldx;
-            for (int w = 0; w < KW; ++w) {
-                const int k = w * 64 + lane;
-                const bool in = k < K;
-                const float t = in ? (xr[k] + beta[k]) : 0.f;
-                const uint64_t sg = __ballot(t > 0.f);
-                const uint64_t nz = __ballot(t != 0.f);
-                const uint64_t st = __ballot(in && (fabsf(t) <= 1.2f));
-                if (lane == 0) {
-                    ls[r * KW + w] = sg;
-                    lz[r * KW + w] = nz;
-                    lt[r * KW + w] = st;
+            for (int w0 = 0; w0 < KW; w0 += 4) {
+                float t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = (w0 + u) * 64 + lane;
+                    const int kc = k < K ? k : K - 1;          // clamped: the loads stay unconditional and batch up
+                    t[u] = xr[kc] + beta[kc];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int w = w0 + u;
+                    const bool in = (w * 64 + lane) < K;
+                    const float tv = in ? t[u] : 0.f;
+                    const uint64_t sg = __ballot(tv > 0.f);
+                    const uint64_t nz = __ballot(tv != 0.f);
+                    const uint64_t st = __ballot(in && (fabsf(tv) <= 1.2f));
+                    if (lane == 0 && w < KW) {
+                        ls[r * KW + w] = sg;
+                        lz[r * KW + w] = nz;
+                        lt[r * KW + w] = st;
+                    }
                 }
             }
         }
@@ -113,7 +127,7 @@ __global__ __launch_bounds__(256) void binlinear_fwd_kernel(const float* __restr
         // ---- saved planes (training), written ROW-SLICED: word [tile*K + k] = bit r of column k for the tile's
         // 64 rows (a 64x64 bit transpose per word by 64 ballots; rows beyond M contribute 0).  This is the layout
         // the backward MFMA kernels consume with one coalesced u64 per lane (gemm_mfma.hip).
-        if (x_sign) {
+        if (x_sign && ob == 0) {
             for (int item = wave; item < 3 * KW; item += 4) {
                 const int pl = item / KW, w = item - pl * KW;
                 const uint64_t* src = (pl == 0) ? ls : ((pl == 1) ? lz : lt);
@@ -158,10 +172,10 @@ __global__ __launch_bounds__(256) void binlinear_fwd_kernel(const float* __restr
     }
 }
 
-// dW[o,k] += scale[o]*GX[o,k]*[|W|<=1.2] ; dscale[o] += sum_k sign(W[o,k])*GX[o,k].  One wave per output row.
+// dW[o,k] (+)= scale[o]*GX[o,k]*[|W|<=1.2] ; dscale[o] (+)= sum_k sign(W[o,k])*GX[o,k].  One wave per output row.
 __global__ __launch_bounds__(256) void binweight_grad_kernel(const float* __restrict__ GX, const float* __restrict__ W,
                                                              const float* __restrict__ scale, int64_t O, int64_t K,
-                                                             float* __restrict__ dW, float* __restrict__ dscale) {
+                                                             float* __restrict__ dW, float* __restrict__ dscale, int accumulate) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -172,10 +186,13 @@ __global__ __launch_bounds__(256) void binweight_grad_kernel(const float* __rest
             const float w = W[o * K + k], g = GX[o * K + k];
             const float s = (w > 0.f) ? 1.f : ((w < 0.f) ? -1.f : 0.f);
             part += s * g;
-            if (dW) dW[o * K + k] += (fabsf(w) <= 1.2f) ? sc * g : 0.f;
+            if (dW) {
+                const float t = (fabsf(w) <= 1.2f) ? sc * g : 0.f;
+                dW[o * K + k] = accumulate ? dW[o * K + k] + t : t;
+            }
         }
         part = wave_sum(part);
-        if (lane == 0 && dscale) dscale[o] += part;
+        if (lane == 0 && dscale) dscale[o] = accumulate ? dscale[o] + part : part;
     }
 }
 
@@ -186,11 +203,18 @@ void launch_fwd(const float* x, int64_t ldx, const float* beta, const uint64_t* 
     int og_shift = 5;
     while ((1 << og_shift) < O && og_shift < 8) ++og_shift;
     const int64_t tiles = svnet_cdiv(M, ROWS);
-    const unsigned grid = (unsigned)(tiles < 256 * 8 ? tiles : 256 * 8);
     const size_t lds_bytes = (size_t)3 * ROWS * KW * sizeof(uint64_t);
+    if (PPM == 1 && tiles <= 8 && O > 32) {
+        // small M: one launch, ceil(O/32) workgroups per row tile (each repeats the cheap packing pass of its tile)
+        const int o_blocks = (O + 31) / 32;
+        hipLaunchKernelGGL((binlinear_fwd_kernel<KWM, PPM>), dim3((unsigned)(tiles * o_blocks)), dim3(256), lds_bytes, st, x, ldx, beta,
+                           w_sign, w_nz, scale, bias, M, K, O, 0, o_blocks, KW, 5, y, xs, xz, xt);
+        return;
+    }
+    const unsigned grid = (unsigned)(tiles < 256 * 8 ? tiles : 256 * 8);
     for (int o_base = 0; o_base < O; o_base += 256 * PPM)
         hipLaunchKernelGGL((binlinear_fwd_kernel<KWM, PPM>), dim3(grid), dim3(256), lds_bytes, st, x, ldx, beta, w_sign, w_nz, scale,
-                           bias, M, K, O, o_base, KW, og_shift, y, xs, xz, xt);
+                           bias, M, K, O, o_base, 1, KW, og_shift, y, xs, xz, xt);
 }
 
 }  // namespace
@@ -227,7 +251,7 @@ extern "C" int svnet_binlinear_fwd_f32(const float* x, int64_t ldx, const float*
     hipStream_t st = (hipStream_t)stream;
 #define SVNET_BL(KWM, PPM) \
     launch_fwd<KWM, PPM>(x, ldx, beta, w_sign, w_nz, scale, bias, M, (int)K, (int)O, (int)KW, y, x_sign, x_nz, x_ste, st)
-    const bool two = O > 256;
+    const bool two = O > 256 && M > 8 * ROWS;      // small M takes the one-launch split over output channels (PPM = 1)
     if (KW <= 2) { if (two) SVNET_BL(2, 2); else SVNET_BL(2, 1); }
     else if (KW <= 4) { if (two) SVNET_BL(4, 2); else SVNET_BL(4, 1); }
     else if (KW <= 8) { if (two) SVNET_BL(8, 2); else SVNET_BL(8, 1); }
@@ -239,10 +263,10 @@ extern "C" int svnet_binlinear_fwd_f32(const float* x, int64_t ldx, const float*
 }
 
 extern "C" int svnet_binweight_grad_f32(const float* GX, const float* W, const float* scale, int64_t O, int64_t K,
-                                        float* dW, float* dscale, void* stream) {
+                                        float* dW, float* dscale, int accumulate, void* stream) {
     SVNET_REQUIRE(GX && W && scale && O > 0 && K > 0, SVNET_E_ARG, "svnet_binweight_grad_f32: bad arguments");
     hipLaunchKernelGGL(binweight_grad_kernel, dim3(svnet_grid(O * 64, 256)), dim3(256), 0, (hipStream_t)stream, GX, W, scale, O, K,
-                       dW, dscale);
+                       dW, dscale, accumulate);
     SVNET_CHECK_LAUNCH("binweight_grad_kernel");
     return SVNET_OK;
 }

@@ -260,8 +260,12 @@ __global__ void edgeblock_coeffs_kernel(const long long* __restrict__ stat_n, co
                                         const float* __restrict__ b1, float* __restrict__ rm1, float* __restrict__ rv1,
                                         const float* __restrict__ g2, const float* __restrict__ b2, float* __restrict__ rm2,
                                         float* __restrict__ rv2, int training, float eps, float momentum,
-                                        float* __restrict__ coef) {
+                                        float* __restrict__ coef, long long* __restrict__ nbt1, long long* __restrict__ nbt2) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && training) {
+        if (nbt1) *nbt1 += 1;
+        if (nbt2) *nbt2 += 1;
+    }
     float* A1 = coef; float* B1 = coef + Os; float* MY = coef + 2 * Os; float* IY = coef + 3 * Os;
     float* Av = coef + 4 * Os; float* Bv = Av + Ov; float* MV = Av + 2 * Ov; float* IV = Av + 3 * Ov;
     if (c < Os) {
@@ -369,14 +373,16 @@ extern "C" int svnet_edgeblock_fwd_f32(const svnet_edgeblock_desc* desc, void* s
 extern "C" int svnet_edgeblock_coeffs_f32(const int64_t* stat_n, const double* stat_v, int64_t E, int64_t Os, int64_t Ov,
                                           const float* scale1, const float* gamma1, const float* beta1, float* running_mean1,
                                           float* running_var1, const float* gamma2, const float* beta2, float* running_mean2,
-                                          float* running_var2, int training, float eps, float momentum, float* coef, void* stream) {
+                                          float* running_var2, int training, float eps, float momentum, float* coef,
+                                          int64_t* num_batches_tracked1, int64_t* num_batches_tracked2, void* stream) {
     SVNET_REQUIRE(scale1 && gamma1 && beta1 && gamma2 && beta2 && coef && E > 0 && Os > 0 && Ov > 0, SVNET_E_ARG, "svnet_edgeblock_coeffs_f32: bad arguments");
     SVNET_REQUIRE(training ? (stat_n && stat_v) : (running_mean1 && running_var1 && running_mean2 && running_var2), SVNET_E_ARG,
                   "svnet_edgeblock_coeffs_f32: missing statistics");
     const int64_t n = Os > Ov ? Os : Ov;
     hipLaunchKernelGGL(edgeblock_coeffs_kernel, dim3((unsigned)svnet_cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream,
                        reinterpret_cast<const long long*>(stat_n), stat_v, E, (int)Os, (int)Ov, scale1, gamma1, beta1, running_mean1,
-                       running_var1, gamma2, beta2, running_mean2, running_var2, training, eps, momentum, coef);
+                       running_var1, gamma2, beta2, running_mean2, running_var2, training, eps, momentum, coef,
+                       reinterpret_cast<long long*>(num_batches_tracked1), reinterpret_cast<long long*>(num_batches_tracked2));
     SVNET_CHECK_LAUNCH("edgeblock_coeffs_kernel");
     return SVNET_OK;
 }

@@ -85,8 +85,9 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
 
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, int64_t M, int64_t C, float eps, float momentum,
                                    float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ rmean,
-                                   float* __restrict__ rvar) {
+                                   float* __restrict__ rvar, long long* __restrict__ nbt) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
     if (c >= C) return;
     const double m = sums[c] / (double)M;
     double var = sums[C + c] / (double)M - m * m;
@@ -285,10 +286,11 @@ extern "C" int svnet_colstats_f64(const float* x, int64_t M, int64_t C, int kind
 }
 
 extern "C" int svnet_bn_finalize_f32(const double* sums, int64_t M, int64_t C, float eps, float momentum, float* mean,
-                                     float* invstd, float* running_mean, float* running_var, void* stream) {
+                                     float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                     void* stream) {
     SVNET_REQUIRE(sums && mean && invstd && M > 0 && C > 0, SVNET_E_ARG, "svnet_bn_finalize_f32: bad arguments");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)svnet_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, M, C, eps,
-                       momentum, mean, invstd, running_mean, running_var);
+                       momentum, mean, invstd, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked));
     SVNET_CHECK_LAUNCH("bn_finalize_kernel");
     return SVNET_OK;
 }

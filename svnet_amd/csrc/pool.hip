@@ -164,7 +164,7 @@ extern "C" int svnet_pool_fwd_f32(const float* x, int64_t outer, int64_t R, int6
     if (outer == 0) return SVNET_OK;
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = outer * inner;
-    if (mode == 1 && R >= 256 && total < 256 * 256) {
+    if (mode == 1 && R >= 256 && total < (1 << 20)) {
         hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * total, st);
         SVNET_REQUIRE(e == hipSuccess, SVNET_E_LAUNCH, "svnet_pool_fwd_f32: memset failed");
         int64_t chunks = svnet_cdiv(256 * 8, outer);
@@ -177,7 +177,7 @@ extern "C" int svnet_pool_fwd_f32(const float* x, int64_t outer, int64_t R, int6
         SVNET_CHECK_LAUNCH("pool_mean_split_kernel");
         return SVNET_OK;
     }
-    if (mode == 0 && R >= 256 && total < 256 * 256 && workspace && workspace_bytes >= (size_t)total * 8 && outer <= 65535) {
+    if (mode == 0 && R >= 256 && total < (1 << 20) && workspace && workspace_bytes >= (size_t)total * 8 && outer <= 65535) {
         // long max-reduction with few outputs (point pooling over N): split the rows over workgroups
         unsigned long long* keys = (unsigned long long*)workspace;
         hipError_t e = hipMemsetAsync(keys, 0, sizeof(unsigned long long) * total, st);
@@ -231,5 +231,94 @@ extern "C" int svnet_smooth_ce_f32(const float* logits, const int64_t* target, i
     SVNET_REQUIRE(e == hipSuccess, SVNET_E_LAUNCH, "svnet_smooth_ce_f32: memset failed");
     hipLaunchKernelGGL(smooth_ce_kernel, dim3(svnet_grid(R * 64, 256, 1024)), dim3(256), 0, st, logits, target, R, C, eps, loss, dlogits);
     SVNET_CHECK_LAUNCH("smooth_ce_kernel");
+    return SVNET_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ gate MLP
+// The per-cloud gate of an SVBlock (sv_layers.py:156-161,179-183): gate = sigmoid(W2 . relu(W0 . (in_scale * gin))).
+// [B, Cin] -> [B, H] -> [B, Ov] with B = 32, Cin <= 2048: one workgroup per cloud does the whole thing (forward) and the
+// whole chain rule (backward) instead of 4 + 8 launch-bound micro-kernels.
+namespace {
+
+__global__ __launch_bounds__(256) void gate_mlp_fwd_kernel(const float* __restrict__ gin, float in_scale, const float* __restrict__ W0,
+                                                           const float* __restrict__ W2, int Cin, int H, int Ov,
+                                                           float* __restrict__ h, float* __restrict__ gate) {
+    __shared__ float hs[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* g = gin + (size_t)b * Cin;
+    for (int j = tid; j < H; j += blockDim.x) {
+        float a = 0.f;
+        for (int c = 0; c < Cin; ++c) a = fmaf(g[c] * in_scale, W0[j * Cin + c], a);
+        a = a > 0.f ? a : 0.f;
+        hs[j] = a;
+        h[(size_t)b * H + j] = a;
+    }
+    __syncthreads();
+    for (int o = tid; o < Ov; o += blockDim.x) {
+        float a = 0.f;
+        for (int j = 0; j < H; ++j) a = fmaf(hs[j], W2[o * H + j], a);
+        gate[(size_t)b * Ov + o] = 1.f / (1.f + expf(-a));
+    }
+}
+
+// dgin[b,c] = out_scale * sum_j dhpre[b,j] W0[j,c];  dW0 += dhpre^T (in_scale*gin);  dW2 += dgpre^T h   (atomics, zero-filled)
+__global__ __launch_bounds__(256) void gate_mlp_bwd_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
+                                                           const float* __restrict__ h, const float* __restrict__ gin, float in_scale,
+                                                           const float* __restrict__ W0, const float* __restrict__ W2, int Cin, int H,
+                                                           int Ov, float out_scale, float* __restrict__ dgin, float* __restrict__ dW0,
+                                                           float* __restrict__ dW2) {
+    __shared__ float dgp[256], dhp[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int o = tid; o < Ov; o += blockDim.x) {
+        const float gt = gate[(size_t)b * Ov + o];
+        dgp[o] = dgate[(size_t)b * Ov + o] * gt * (1.f - gt);
+    }
+    __syncthreads();
+    for (int j = tid; j < H; j += blockDim.x) {
+        float a = 0.f;
+        for (int o = 0; o < Ov; ++o) a = fmaf(dgp[o], W2[o * H + j], a);
+        dhp[j] = h[(size_t)b * H + j] > 0.f ? a : 0.f;
+    }
+    __syncthreads();
+    for (int e = tid; e < Ov * H; e += blockDim.x) {
+        const int o = e / H, j = e - o * H;
+        atomicAdd(&dW2[e], dgp[o] * h[(size_t)b * H + j]);
+    }
+    for (int e = tid; e < H * Cin; e += blockDim.x) {
+        const int j = e / Cin, c = e - j * Cin;
+        atomicAdd(&dW0[e], dhp[j] * gin[(size_t)b * Cin + c] * in_scale);
+    }
+    if (dgin) {
+        for (int c = tid; c < Cin; c += blockDim.x) {
+            float a = 0.f;
+            for (int j = 0; j < H; ++j) a = fmaf(dhp[j], W0[j * Cin + c], a);
+            dgin[(size_t)b * Cin + c] = a * out_scale;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int svnet_gate_mlp_fwd_f32(const float* gin, float in_scale, const float* W0, const float* W2, int64_t B, int64_t Cin,
+                                      int64_t H, int64_t Ov, float* h, float* gate, void* stream) {
+    SVNET_REQUIRE(gin && W0 && W2 && h && gate && B >= 0 && Cin > 0 && H > 0 && Ov > 0, SVNET_E_ARG, "svnet_gate_mlp_fwd_f32: bad arguments");
+    SVNET_REQUIRE(H <= 256 && Ov <= 256, SVNET_E_UNSUPPORTED, "svnet_gate_mlp_fwd_f32: H, Ov must be <= 256");
+    if (B == 0) return SVNET_OK;
+    hipLaunchKernelGGL(gate_mlp_fwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, gin, in_scale, W0, W2, (int)Cin, (int)H,
+                       (int)Ov, h, gate);
+    SVNET_CHECK_LAUNCH("gate_mlp_fwd_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_gate_mlp_bwd_f32(const float* dgate, const float* gate, const float* h, const float* gin, float in_scale,
+                                      const float* W0, const float* W2, int64_t B, int64_t Cin, int64_t H, int64_t Ov, float out_scale,
+                                      float* dgin, float* dW0, float* dW2, void* stream) {
+    SVNET_REQUIRE(dgate && gate && h && gin && W0 && W2 && dW0 && dW2 && B >= 0 && Cin > 0 && H > 0 && Ov > 0, SVNET_E_ARG,
+                  "svnet_gate_mlp_bwd_f32: bad arguments");
+    SVNET_REQUIRE(H <= 256 && Ov <= 256, SVNET_E_UNSUPPORTED, "svnet_gate_mlp_bwd_f32: H, Ov must be <= 256");
+    if (B == 0) return SVNET_OK;
+    hipLaunchKernelGGL(gate_mlp_bwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, dgate, gate, h, gin, in_scale, W0, W2,
+                       (int)Cin, (int)H, (int)Ov, out_scale, dgin, dW0, dW2);
+    SVNET_CHECK_LAUNCH("gate_mlp_bwd_kernel");
     return SVNET_OK;
 }

@@ -155,8 +155,12 @@ __global__ void xyzblock_coeffs_kernel(const double* __restrict__ stat_y, const 
                                        const float* __restrict__ g1, const float* __restrict__ b1, float* __restrict__ rm1,
                                        float* __restrict__ rv1, const float* __restrict__ g2, const float* __restrict__ b2,
                                        float* __restrict__ rm2, float* __restrict__ rv2, int training, float eps, float momentum,
-                                       float* __restrict__ coef) {
+                                       float* __restrict__ coef, long long* __restrict__ nbt1, long long* __restrict__ nbt2) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && training) {
+        if (nbt1) *nbt1 += 1;
+        if (nbt2) *nbt2 += 1;
+    }
     for (int part = 0; part < 2; ++part) {
         const int C = part == 0 ? Os : Ov;
         if (c >= C) continue;
@@ -418,14 +422,16 @@ extern "C" int svnet_xyzblock_fwd_f32(const svnet_xyzblock_desc* desc, void* str
 extern "C" int svnet_xyzblock_coeffs_f32(const double* stat_y, const double* stat_v, int64_t E, int64_t Os, int64_t Ov,
                                          const float* gamma1, const float* beta1, float* running_mean1, float* running_var1,
                                          const float* gamma2, const float* beta2, float* running_mean2, float* running_var2,
-                                         int training, float eps, float momentum, float* coef, void* stream) {
+                                         int training, float eps, float momentum, float* coef, int64_t* num_batches_tracked1,
+                                         int64_t* num_batches_tracked2, void* stream) {
     SVNET_REQUIRE(gamma1 && beta1 && gamma2 && beta2 && coef && E > 0 && Os > 0 && Ov > 0, SVNET_E_ARG, "svnet_xyzblock_coeffs_f32: bad arguments");
     SVNET_REQUIRE(training ? (stat_y && stat_v) : (running_mean1 && running_var1 && running_mean2 && running_var2), SVNET_E_ARG,
                   "svnet_xyzblock_coeffs_f32: missing statistics");
     const int64_t n = Os > Ov ? Os : Ov;
     hipLaunchKernelGGL(xyzblock_coeffs_kernel, dim3((unsigned)svnet_cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream, stat_y, stat_v, E,
                        (int)Os, (int)Ov, gamma1, beta1, running_mean1, running_var1, gamma2, beta2, running_mean2, running_var2,
-                       training, eps, momentum, coef);
+                       training, eps, momentum, coef, reinterpret_cast<long long*>(num_batches_tracked1),
+                       reinterpret_cast<long long*>(num_batches_tracked2));
     SVNET_CHECK_LAUNCH("xyzblock_coeffs_kernel");
     return SVNET_OK;
 }

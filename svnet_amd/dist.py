@@ -27,6 +27,28 @@ class GradBucket:
     def zero(self):
         self.flat.zero_()
 
+    # "assign then pack" mode: instead of zeroing the bucket and letting autograd ADD every parameter gradient into its
+    # view (one small kernel per parameter), drop the views before the backward (autograd then just keeps each produced
+    # gradient tensor) and gather them into the bucket with one batched copy afterwards.
+    def begin(self):
+        for p in self.params:
+            p.grad = None
+
+    def pack(self):
+        pieces = []
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            g = p.grad
+            pieces.append(g.reshape(-1) if g is not None else torch.zeros(n, dtype=self.flat.dtype, device=self.flat.device))
+            off += n
+        torch.cat(pieces, out=self.flat)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
     def all_reduce_mean(self):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)

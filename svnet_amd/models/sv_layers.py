@@ -32,9 +32,8 @@ _ACT_NONE, _ACT_LEAKY, _ACT_RELU = 0, 1, 2
 def batch_norm_act(bn, x, act=_ACT_NONE, slope=0.2):
     """nn.BatchNorm1d `bn` (+ activation) over the rows of x [..., C] in one fused pass."""
     training = bn.training or bn.running_mean is None
-    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-    return _ops.BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, act, slope)
+    nbt = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None    # += 1 inside the finalize kernel
+    return _ops.BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, act, slope, nbt)
 
 
 class Linear(nn.Linear):
@@ -96,11 +95,10 @@ class VectorBN(nn.Module):
         '''
         bn = self.bn
         training = bn.training or bn.running_mean is None
-        if bn.training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+        nbt = bn.num_batches_tracked if bn.training else None                                 # += 1 inside the finalize kernel
         rows = v.numel() // (3 * v.shape[-1])
         rows_per_batch = max(rows // v.shape[0], 1)
-        return _ops.VBN.apply(v, bn.weight, bn.bias, bn.running_mean, bn.running_var, gate, rows_per_batch, training)
+        return _ops.VBN.apply(v, bn.weight, bn.bias, bn.running_mean, bn.running_var, gate, rows_per_batch, training, nbt)
 
 
 class Vector2Scalar(nn.Module):
@@ -168,13 +166,10 @@ class PendingXyzBlock:
             return None
         b, e = self.block, self.edges
         bn1, bn2 = b.bn1, b.bn2.bn
-        if b.training:
-            bn1.num_batches_tracked.add_(1)
-            bn2.num_batches_tracked.add_(1)
         s, v = _ops.XyzBlock.apply(
             e.pts, e.idx, e.k, b.training, self.s_lazy.v2s.linear.weight, b.v2s.linear.weight, b.linear1.weight, bn1.weight,
             bn1.bias, bn1.running_mean, bn1.running_var, b.linear2.weight, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var,
-            b.gate[0].weight, b.gate[2].weight)
+            b.gate[0].weight, b.gate[2].weight, bn1.num_batches_tracked, bn2.num_batches_tracked)
         return (s.unsqueeze(2), v.unsqueeze(2)) if keepdim else (s, v)
 
     def materialize(self):
@@ -208,13 +203,11 @@ class PendingEdgeBlock:
         training = b.training
         if not training and torch.is_grad_enabled() and (e.s.requires_grad or any(p.requires_grad for p in b.parameters())):
             return None            # eval-mode gradients (bare sign(): zero STE gradient) take the layer-wise path
-        if training:
-            bn1.num_batches_tracked.add_(1)
-            bn2.num_batches_tracked.add_(1)
         s, v = _ops.EdgeBlock.apply(
             e.s, e.v, e.idx, e.k, training, b.v2s.linear.weight, b.v2s.linear.scale, b.linear1.weight, b.linear1.beta,
             b.linear1.scale, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, b.linear2.weight, b.linear2.scale,
-            bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, b.gate[0].weight, b.gate[2].weight)
+            bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, b.gate[0].weight, b.gate[2].weight,
+            bn1.num_batches_tracked, bn2.num_batches_tracked)
         return (s.unsqueeze(2), v.unsqueeze(2)) if keepdim else (s, v)
 
     def materialize(self):
@@ -257,6 +250,8 @@ class SVBlock(nn.Module):
 
     def _gate(self, s):
         pooled = _ops.Pool.apply(s.reshape(s.shape[0], -1, s.shape[-1]), 1, 1)          # mean over all rows of a cloud
+        if self.gate[0].out_features <= 256 and self.gate[2].out_features <= 256:
+            return _ops.GateMLP.apply(pooled, self.gate[0].weight, self.gate[2].weight)  # -> [B, Cv_out]
         h = _ops.Act.apply(_ops.FpLinear.apply(pooled, self.gate[0].weight, None), 1)   # ReLU
         return _ops.Act.apply(_ops.FpLinear.apply(h, self.gate[2].weight, None), 2)     # Sigmoid -> [B, Cv_out]
 

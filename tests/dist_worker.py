@@ -26,6 +26,13 @@ def main():
     assert torch.allclose(torch.cat([p.grad.reshape(-1) for p in net.parameters()]), want, atol=1e-7)
     bucket.zero()
     assert float(bucket.flat.abs().sum()) == 0.0
+    # assign-then-pack mode gives the same flat gradient as zero-then-accumulate
+    bucket.begin()
+    net(x).pow(2).mean().backward()
+    bucket.pack()
+    assert torch.allclose(bucket.flat, local, atol=1e-7)
+    for p in net.parameters():
+        assert p.grad.data_ptr() >= bucket.flat.data_ptr()
     dist.barrier()
     dist.destroy_process_group()
     print("OK rank", rank)
