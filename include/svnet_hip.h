@@ -132,6 +132,9 @@ typedef struct svnet_edgeblock_desc {
     int32_t* n_max; int32_t* n_min; uint8_t* slot_max; uint8_t* slot_min;
     float* mv; float* mvn;
     int64_t* stat_n; double* stat_v; float* gate_sum;
+    /* kept for the backward (both or none): n16 [E,Os] = the integer popcount sum of every edge row, planes [E,3,5] = the
+     * sign | non-zero | STE (|x+beta| <= 1.2) bit planes of the binarized edge feature in the fused bit order            */
+    int16_t* n16; uint64_t* planes;
 } svnet_edgeblock_desc;
 int svnet_edgeblock_prepare_f32(const float* W, const float* beta, int64_t Os, int64_t Cs, int64_t Cv, uint64_t* w_sign,
                                 uint64_t* w_nz, float* beta_perm /*[5*64]*/, void* stream);
@@ -154,8 +157,8 @@ int svnet_edgeblock_apply_f32(const int32_t* n_max, const int32_t* n_min, const 
                               float slope, float* s_out, float* v_out, void* stream);
 
 /* Backward of the fused edge block: a point-level prelude reduces the batch-statistic terms of both BatchNorms,
- * then ONE pass over the edges recomputes the forward quantities from the point tables and produces all gradients
- * (csrc/edgeblock_bwd.hip).  Outputs of svnet_edgeblock_bwd_f32 (caller zero-fills every *_acc, dvc, dzc, dbeta_perm):
+ * then the edge pass produces all gradients from the point tables and the n16 / planes the forward kept
+ * (csrc/edgeblock_bwd.hip).  Outputs of svnet_edgeblock_bwd_f32 (caller zero-fills every *_acc, dzc, dbeta_perm):
  *   dn_out [E,Os]            dL/d(scale*n) per edge          -> GX = dn_out^T . x_b via svnet_gemm_f32 (ternary A)
  *   x_sign32/x_nz32          row-sliced planes of x_b in fused column order, [ceil(E/64), 320] uint64 viewed as uint32
  *   ds_acc [P,Cs], dv_acc [P,3,Cv]   gradients of the point tables (binarized + gate + v2s paths)
@@ -165,8 +168,8 @@ int svnet_edgeblock_apply_f32(const int32_t* n_max, const int32_t* n_min, const 
 typedef struct svnet_edgeblock_bwd_desc {
     int64_t B, N, k;
     int Cs, Cv, Os, Ov;
-    const float* s; const float* v; const int64_t* idx; const float* zz; const float* ut;
-    const uint64_t* w_sign; const uint64_t* w_nz; const float* beta_perm;
+    const float* v; const int64_t* idx; const float* zz; const float* ut;
+    const int16_t* n16; const uint64_t* planes;   /* kept by svnet_edgeblock_fwd_f32 */
     const uint16_t* w1bt;        /* svnet_edgeblock_wbt_bf16: sign(W1) as bf16 [320][Os] */
     const float* scale1;
     const uint8_t* slot_max; const uint8_t* slot_min;

@@ -49,6 +49,7 @@ class EdgeBlockDesc(ctypes.Structure):
         ("n_max", c_p), ("n_min", c_p), ("slot_max", c_p), ("slot_min", c_p),
         ("mv", c_p), ("mvn", c_p),
         ("stat_n", c_p), ("stat_v", c_p), ("gate_sum", c_p),
+        ("n16", c_p), ("planes", c_p),
     ]
 
 
@@ -57,8 +58,8 @@ class EdgeBlockBwdDesc(ctypes.Structure):
     _fields_ = [
         ("B", c_i64), ("N", c_i64), ("k", c_i64),
         ("Cs", c_int), ("Cv", c_int), ("Os", c_int), ("Ov", c_int),
-        ("s", c_p), ("v", c_p), ("idx", c_p), ("zz", c_p), ("ut", c_p),
-        ("w_sign", c_p), ("w_nz", c_p), ("beta_perm", c_p),
+        ("v", c_p), ("idx", c_p), ("zz", c_p), ("ut", c_p),
+        ("n16", c_p), ("planes", c_p),
         ("w1bt", c_p),
         ("scale1", c_p),
         ("slot_max", c_p), ("slot_min", c_p),

@@ -589,6 +589,12 @@ class EdgeBlock(torch.autograd.Function):
         d.w_sign, d.w_nz, d.beta_perm = _p(w_sign), _p(w_nz), _p(beta_perm)
         d.n_max, d.n_min, d.slot_max, d.slot_min = _p(n_max), _p(n_min), _p(slot_max), _p(slot_min)
         d.mv, d.mvn, d.stat_n, d.stat_v, d.gate_sum = _p(mv), _p(mvn), _p(stat_n), _p(stat_v), _p(gate_sum)
+        # kept for the backward instead of any fp32 edge tensor: the integer sum n (2 B per edge-channel) and the sign /
+        # non-zero / STE bit planes of the binarized edge feature (120 B per edge)
+        keep = training and any(ctx.needs_input_grad)
+        n16 = torch.empty((E, Os), dtype=torch.int16, device=dev) if keep else None
+        planes = torch.empty((E, 15), dtype=torch.int64, device=dev) if keep else None
+        d.n16, d.planes = _p(n16), _p(planes)
         call("svnet_edgeblock_fwd_f32", ctypes.byref(d), _stream())
 
         # gate MLP on the mean edge scalar (sv_layers.py:156-161,179-183): one workgroup per cloud
@@ -604,7 +610,7 @@ class EdgeBlock(torch.autograd.Function):
         v_out = torch.empty((B, N, 3, Ov), **f32)
         call("svnet_edgeblock_apply_f32", _p(n_max), _p(n_min), _p(mv), _p(mvn), _p(coef), _p(gate), P, N, Os, Ov, 0.2, _p(s_out),
              _p(v_out), _stream())
-        ctx.save_for_backward(s, v, idx, zz, ut, w_sign, w_nz, beta_perm, n_max, n_min, slot_max, slot_min, mv, mvn, coef, gate, h,
+        ctx.save_for_backward(v, idx, zz, ut, w_sign, w_nz, n16, planes, n_max, n_min, slot_max, slot_min, mv, mvn, coef, gate, h,
                               gate_sum, wv, scv, W1c, sc1, W2c, sc2f, Wzc, sczf, g1, g2, Wg0c, Wg2c)
         ctx.meta = (B, N, k, Cs, Cv, Os, Ov, bool(training), scale1.shape, sc2.shape, scz.shape)
         return s_out, v_out
@@ -612,11 +618,13 @@ class EdgeBlock(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gs, gv):
         from ._lib import EdgeBlockBwdDesc
-        (s, v, idx, zz, ut, w_sign, w_nz, beta_perm, n_max, n_min, slot_max, slot_min, mv, mvn, coef, gate, h, gin, wv, scv,
+        (v, idx, zz, ut, w_sign, w_nz, n16, planes, n_max, n_min, slot_max, slot_min, mv, mvn, coef, gate, h, gin, wv, scv,
          W1, sc1, W2, sc2, Wz, scz, g1, g2, Wg0, Wg2) = ctx.saved_tensors
         B, N, k, Cs, Cv, Os, Ov, training, sh1, sh2, shz = ctx.meta
         P, E = B * N, B * N * k
-        dev = s.device
+        dev = v.device
+        if n16 is None:
+            raise RuntimeError("EdgeBlock.backward: the forward ran in eval mode (no STE gradient exists, sv_layers.py:38-45)")
         f32 = dict(dtype=torch.float32, device=dev)
         F = torch.float32
         gs = _f32c(gs).reshape(P, Os)
@@ -654,8 +662,8 @@ class EdgeBlock(torch.autograd.Function):
         d = EdgeBlockBwdDesc()
         d.B, d.N, d.k = B, N, k
         d.Cs, d.Cv, d.Os, d.Ov = Cs, Cv, Os, Ov
-        d.s, d.v, d.idx, d.zz, d.ut = _p(s), _p(v), _p(idx), _p(zz), _p(ut)
-        d.w_sign, d.w_nz, d.beta_perm, d.w1bt, d.scale1 = _p(w_sign), _p(w_nz), _p(beta_perm), _p(wbt), _p(sc1)
+        d.v, d.idx, d.zz, d.ut = _p(v), _p(idx), _p(zz), _p(ut)
+        d.n16, d.planes, d.w1bt, d.scale1 = _p(n16), _p(planes), _p(wbt), _p(sc1)
         d.slot_max, d.slot_min, d.coef, d.gate = _p(slot_max), _p(slot_min), _p(coef), _p(gate)
         d.gy, d.bcoef, d.gv, d.gconst = _p(gy), _p(bcoef), _p(gv), _p(gconst)
         d.dn_out, d.x_sign32, d.x_nz32 = _p(dn_out), _p(x_sign), _p(x_nz)

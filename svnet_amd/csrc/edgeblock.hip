@@ -108,6 +108,8 @@ __global__ __launch_bounds__(256) void edgeblock_fwd_kernel(FwdArgs fa) {
     const int cm = diff_lane ? lane : lane - Cv;
     const bool o_lane = lane < Ov;
 
+    const bool save = d.planes != nullptr;   // training: keep n and the ternary / STE planes of every edge for the backward
+
     long long sn[OP], sn2[OP];
 #pragma unroll
     for (int op = 0; op < OP; ++op) sn[op] = sn2[op] = 0;
@@ -120,6 +122,7 @@ __global__ __launch_bounds__(256) void edgeblock_fwd_kernel(FwdArgs fa) {
         gs_cen += s_i;
         const float tc = s_i + bc;
         const uint64_t csg = __ballot(s_lane && tc > 0.f), cnz = __ballot(s_lane && tc != 0.f);
+        const uint64_t cst = save ? __ballot(s_lane && fabsf(tc) <= 1.2f) : 0ull;
         int base[OP];
 #pragma unroll
         for (int op = 0; op < OP; ++op) base[op] = tdot(csg, cnz, wsg[op][1], wnz[op][1]);
@@ -170,12 +173,24 @@ __global__ __launch_bounds__(256) void edgeblock_fwd_kernel(FwdArgs fa) {
             for (int dd = 0; dd < 3; ++dd)
 #pragma unroll
                 for (int jz = 0; jz < 3; ++jz) z[dd][jz] = zj[dd * 3 + jz] + zi[dd][jz];
-            uint64_t vsg[3], vnz[3];
+            uint64_t vsg[3], vnz[3], vst[3];
 #pragma unroll
             for (int jz = 0; jz < 3; ++jz) {
                 const float tv = ve[0] * z[0][jz] + ve[1] * z[1][jz] + ve[2] * z[2][jz] + bv[jz];
                 vsg[jz] = __ballot(v2_lane && tv > 0.f);
                 vnz[jz] = __ballot(v2_lane && tv != 0.f);
+                vst[jz] = save ? __ballot(v2_lane && fabsf(tv) <= 1.2f) : 0ull;
+            }
+            const int64_t e = gp * k + t;
+            if (save) {  // wave-uniform.  planes[e][plane][word]: lane 5*plane + word holds one 64-bit word of the edge row
+                const uint64_t dst = __ballot(s_lane && fabsf(td) <= 1.2f);
+                uint64_t val = dsg;
+                val = lane == 1 ? csg : val;  val = lane == 2 ? vsg[0] : val;  val = lane == 3 ? vsg[1] : val;  val = lane == 4 ? vsg[2] : val;
+                val = lane == 5 ? dnz : val;  val = lane == 6 ? cnz : val;     val = lane == 7 ? vnz[0] : val;  val = lane == 8 ? vnz[1] : val;
+                val = lane == 9 ? vnz[2] : val;
+                val = lane == 10 ? dst : val; val = lane == 11 ? cst : val;    val = lane == 12 ? vst[0] : val; val = lane == 13 ? vst[1] : val;
+                val = lane == 14 ? vst[2] : val;
+                if (lane < 3 * NW) d.planes[e * (3 * NW) + lane] = val;
             }
 #pragma unroll
             for (int op = 0; op < OP; ++op) {
@@ -186,6 +201,7 @@ __global__ __launch_bounds__(256) void edgeblock_fwd_kernel(FwdArgs fa) {
                 if (n < nmin[op]) { nmin[op] = n; smin[op] = t; }
                 sn[op] += n;
                 sn2[op] += n * n;
+                if (save && lane + 64 * op < Os) d.n16[e * Os + lane + 64 * op] = (int16_t)n;   // |n| <= 320
             }
             if (o_lane) {
                 const float vp0 = u0 + ub[0], vp1 = u1 + ub[1], vp2 = u2 + ub[2];
@@ -351,6 +367,7 @@ extern "C" int svnet_edgeblock_fwd_f32(const svnet_edgeblock_desc* desc, void* s
     SVNET_REQUIRE(d.s && d.v && d.idx && d.zz && d.ut && d.w_sign && d.w_nz && d.beta_perm && d.n_max && d.n_min && d.slot_max &&
                       d.slot_min && d.mv && d.mvn && d.gate_sum, SVNET_E_ARG, "svnet_edgeblock_fwd_f32: null pointer");
     SVNET_REQUIRE((d.stat_n == nullptr) == (d.stat_v == nullptr), SVNET_E_ARG, "svnet_edgeblock_fwd_f32: pass both stat buffers or none");
+    SVNET_REQUIRE((d.n16 == nullptr) == (d.planes == nullptr), SVNET_E_ARG, "svnet_edgeblock_fwd_f32: pass both n16 and planes or none");
     SVNET_REQUIRE(d.B >= 0 && d.N > 0 && d.k > 0 && d.k <= 255, SVNET_E_ARG, "svnet_edgeblock_fwd_f32: bad sizes");
     SVNET_REQUIRE(d.Cs > 0 && d.Cs <= 64 && d.Cv > 0 && 2 * d.Cv <= 64 && d.Os > 0 && d.Os <= 128 && d.Ov > 0 && d.Ov <= 64,
                   SVNET_E_UNSUPPORTED, "svnet_edgeblock_fwd_f32: channel counts outside Cs<=64, 2Cv<=64, Os<=128, Ov<=64");

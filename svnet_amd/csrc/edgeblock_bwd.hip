@@ -1,17 +1,20 @@
-// Backward of the fused edge block (csrc/edgeblock.hip): one pass over the edges that RECOMPUTES the forward
-// quantities from the point tables (nothing edge-sized was saved) and produces every gradient.
+// Backward of the fused edge block (csrc/edgeblock.hip): every gradient of the layer from the point tables plus 2.4 B per
+// edge-channel kept by the forward (no fp32 edge tensor exists in either direction).
 //
 // Autograd of  get_graph_feature_sv -> SVBlock(binary) -> svpool  (sv_util.py:90-132, sv_layers.py:172-196), with the
 // batch-statistic terms of both BatchNorms reduced at POINT level first (edgeblock_bwd_prelude / _coeffs):
 //   scalar path: dL/dy_pre[e,o] = cs[o] * (g[e,o] - m1[o] - xhat[e,o]*m2[o]),  g = gy[p,o] on the arg-max edge, else 0
 //   vector path: dL/dn'[e,c]    = direct + c0[c] + c1[c]*n'[e,c]
-// Workgroup = 4 waves = one tile of 32 consecutive edge rows:
-//   phase A (lanes = channels, 8 edges per wave): gather, re-binarize (ballots), popcount n, dL/dy_pre -> LDS (+ HBM for
-//            the weight-gradient GEMM), ternary planes -> LDS -> row-sliced 32-bit halves in HBM; whole vector path
-//            (dv' scattered to dU with float atomics, one contiguous row segment per wave-instruction);
-//   phase B (MFMA): dx_b[32 x 320] = dy[32 x Os] . sign(W1)[Os x 320] on v_mfma_f32_32x32x16_bf16, exact 3-way split
-//            of dy, STE mask applied from the LDS planes, result to LDS;
-//   phase C (lanes = channels): beta / s / v2s backward, scatter-add to the point tables.
+// The forward kept n (int16) and the ternary / STE bit planes of every edge row, so nothing is re-binarized here.
+// Two kernels:
+//   edgeblock_bwd_vec_kernel (wave per point): the whole vector path; dv' scattered to dU with float atomics (contiguous
+//            row segments), the centre sums written once per point;
+//   edgeblock_bwd_kernel (workgroup = 4 waves = one tile of 32 consecutive edge rows):
+//     phase A (elementwise, coalesced): dL/dy_pre from n -> HBM (operand of the weight-gradient GEMM) and LDS; planes -> LDS
+//              -> row-sliced 32-bit halves in HBM (the other operand);
+//     phase B (MFMA): dx_b[32 x 320] = dy[32 x Os] . sign(W1)[Os x 320] on v_mfma_f32_32x32x16_bf16, exact 3-way split
+//              of dy, STE mask applied from the LDS planes, result to LDS;
+//     phase C (lanes = channels): beta / s / v2s backward, scatter-add to the point tables.
 // The weight gradient GX = dy^T . x_b is left to mfma_tn_kernel (gemm_mfma.hip) on the dn_out + planes this kernel
 // writes (4 B + 0.25 B per edge-channel instead of the 4 B fp32 input the layer-wise path keeps).
 #include <stdlib.h>
@@ -148,29 +151,116 @@ __global__ void edgeblock_bwd_coeffs_kernel(const float* __restrict__ red, const
     }
 }
 
-// ---------------------------------------------------------------------------------------------- edge pass
-// Everything one lane needs for one edge row.  The row index is wave-uniform (readfirstlane'd wave id), so gp / gj /
+// ---------------------------------------------------------------------------------------------- vector path
+// dL/dv' of every edge (v' = U_j - U_i + T_i, out = gate * mean_k v'*(Av + Bv/n'), n' = |v'| + eps):
+//   du_acc[j] += dv' (float atomics, contiguous Ov-float segments),  dvc[i] = sum_k dv' (plain store: one wave owns a point).
+// Wave per point like the forward; lanes = (edge slot g, channel c) with G = 64/Ov edges per wave-instruction.
+struct VecArgs {
+    svnet_edgeblock_bwd_desc d;
+    int waves_per_cloud, points_per_wave;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void edgeblock_bwd_vec_kernel(VecArgs va) {
+    const svnet_edgeblock_bwd_desc& d = va.d;
+    const int lane = threadIdx.x & 63;
+    int64_t blk = blockIdx.x;
+    if ((d.B & 7) == 0 && (va.waves_per_cloud & 3) == 0) {   // XCD-aware order, as in edgeblock_fwd_kernel
+        const int64_t bpc = va.waves_per_cloud >> 2, xcd = blk & 7, slot = blk >> 3;
+        blk = ((slot / bpc) * 8 + xcd) * bpc + (slot % bpc);
+    }
+    const int64_t wave_g = blk * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t b = wave_g / va.waves_per_cloud;
+    if (b >= d.B) return;
+    const int wi = (int)(wave_g - b * va.waves_per_cloud);
+    const int p_begin = wi * va.points_per_wave, p_end = min((int)d.N, p_begin + va.points_per_wave);
+    const int Os = d.Os, Ov = d.Ov, k = (int)d.k;
+    const int G = 64 / Ov, g = lane / Ov, c = lane - g * Ov;
+    const bool act = g < G;
+    const float* Av = d.coef + 4 * Os; const float* Bv = Av + Ov;
+    const float* C0 = d.bcoef + 3 * Os; const float* C1 = C0 + Ov;
+    const float avc = Av[c], bvc = Bv[c], c0 = C0[c], c1 = C1[c];
+    const float gtk = d.gate[b * Ov + c] / (float)k;
+
+    for (int p = p_begin; p < p_end; ++p) {
+        const int64_t gp = b * d.N + p;
+        const float* ui = d.ut + gp * 6 * Ov;
+        const float ub0 = ui[0 * 2 * Ov + Ov + c] - ui[0 * 2 * Ov + c];   // T_i - U_i
+        const float ub1 = ui[1 * 2 * Ov + Ov + c] - ui[1 * 2 * Ov + c];
+        const float ub2 = ui[2 * 2 * Ov + Ov + c] - ui[2 * 2 * Ov + c];
+        const float ge0 = d.gv[(gp * 3 + 0) * Ov + c] * gtk, ge1 = d.gv[(gp * 3 + 1) * Ov + c] * gtk, ge2 = d.gv[(gp * 3 + 2) * Ov + c] * gtk;
+        float cv0 = 0.f, cv1 = 0.f, cv2 = 0.f;
+        // neighbour rows one iteration ahead
+        int64_t n_gj; bool n_ok; float n_u0, n_u1, n_u2;
+#define SVNET_LOAD_U(T0)                                                                            \
+    do {                                                                                            \
+        const int t_ = (T0) + g;                                                                    \
+        n_ok = act && t_ < k;                                                                       \
+        int64_t jl_ = n_ok ? d.idx[gp * k + t_] : 0;                                                \
+        if ((uint64_t)jl_ >= (uint64_t)d.N) { /* corrupted neighbour id: never dereference it */   \
+            if (d.debug && c == 0) {                                                                \
+                if (atomicAdd(reinterpret_cast<unsigned long long*>(d.debug), 1ull) == 0ull) {      \
+                    d.debug[1] = gp * k + t_; d.debug[2] = jl_; d.debug[3] = d.N;                   \
+                }                                                                                   \
+            }                                                                                       \
+            n_ok = false; jl_ = 0;                                                                  \
+        }                                                                                           \
+        n_gj = b * d.N + jl_;                                                                       \
+        const float* uj_ = d.ut + n_gj * 6 * Ov;                                                    \
+        n_u0 = uj_[0 * 2 * Ov + c]; n_u1 = uj_[1 * 2 * Ov + c]; n_u2 = uj_[2 * 2 * Ov + c];         \
+    } while (0)
+        SVNET_LOAD_U(0);
+        for (int t0 = 0; t0 < k; t0 += G) {
+            const int64_t gj = n_gj;
+            const bool ok = n_ok;
+            const float u0 = n_u0, u1 = n_u1, u2 = n_u2;
+            if (t0 + G < k) SVNET_LOAD_U(t0 + G);
+            const float vp0 = u0 + ub0, vp1 = u1 + ub1, vp2 = u2 + ub2;
+            const float nv = sqrtf(vp0 * vp0 + vp1 * vp1 + vp2 * vp2);
+            const float nn = nv + VEPS;
+            const float q = avc + bvc / nn;
+            const float gdot = ge0 * vp0 + ge1 * vp1 + ge2 * vp2;
+            const float dnn = -gdot * bvc / (nn * nn) + c0 + c1 * nn;
+            const float kk = nv > 0.f ? dnn / nv : 0.f;
+            const float d0 = ge0 * q + kk * vp0, d1 = ge1 * q + kk * vp1, d2 = ge2 * q + kk * vp2;
+            if (ok) {
+                ATOMIC_ADD(&d.du_acc[(gj * 3 + 0) * Ov + c], d0);
+                ATOMIC_ADD(&d.du_acc[(gj * 3 + 1) * Ov + c], d1);
+                ATOMIC_ADD(&d.du_acc[(gj * 3 + 2) * Ov + c], d2);
+                cv0 += d0; cv1 += d1; cv2 += d2;
+            }
+        }
+#undef SVNET_LOAD_U
+        for (int gg = 1; gg < G; ++gg) {   // fold the edge slots: lanes g*Ov + c -> lane c
+            const int src = (lane + gg * Ov) & 63;
+            const float t0 = __shfl(cv0, src), t1 = __shfl(cv1, src), t2 = __shfl(cv2, src);   // all lanes take part
+            if (lane < Ov) { cv0 += t0; cv1 += t1; cv2 += t2; }
+        }
+        if (lane < Ov) {
+            d.dvc[(gp * 3 + 0) * Ov + lane] = cv0;
+            d.dvc[(gp * 3 + 1) * Ov + lane] = cv1;
+            d.dvc[(gp * 3 + 2) * Ov + lane] = cv2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- edge pass (tiles)
+// What one lane needs for one edge row in phase C.  The row index is wave-uniform (readfirstlane'd wave id), so gp / gj /
 // the zz rows go through scalar loads and SGPR-based addressing.
 struct EdgeIn {
     int64_t gp, gj, b;
-    int t;
     bool valid;
-    float si, sj;                                 // lane c < Cs
     float vi0, vi1, vi2, vj0, vj1, vj2;           // lane c2 < 2Cv (vj: diff lanes only)
     float z0, z1, z2, z3, z4, z5, z6, z7, z8;     // z[d*3+jz] = Zp_j - Zp_i + Zq_i
-    float ui0, ui1, ui2, uj0, uj1, uj2;           // lane c' < Ov: ui = T_i - U_i, uj = U_j
-    float gv0, gv1, gv2, gt;                      // lane c' < Ov: upstream dL/dv_out, gate   (phase A)
-    float gy0, gy1; int slot0, slot1;             // lane o (+64): pooled-edge gradient and slot (phase A)
-    float gc0, gc1;                               // lane c < Cs: gate-path constants          (phase C)
+    float gc0, gc1;                               // lane c < Cs: gate-path constants
 };
 
-__device__ __forceinline__ void load_edge(const svnet_edgeblock_bwd_desc& d, int64_t e, int64_t E, int lane, bool s_lane,
-                                          bool v2_lane, bool diff_lane, bool o_lane, int cm, bool want_u, bool pos0, bool pos1, EdgeIn& in) {
-    const int Cs = d.Cs, Cv = d.Cv, Ov = d.Ov, k = (int)d.k;
+__device__ __forceinline__ void load_edge(const svnet_edgeblock_bwd_desc& d, int64_t e, int64_t E, int lane, bool v2_lane, int cm,
+                                          EdgeIn& in) {
+    const int Cs = d.Cs, Cv = d.Cv, k = (int)d.k;
     in.valid = e < E;
     if (!in.valid) return;
     in.gp = e / k;
-    in.t = (int)(e - in.gp * k);
     in.b = in.gp / d.N;
     const int64_t jloc = d.idx[e];
     if ((uint64_t)jloc >= (uint64_t)d.N) {  // corrupted neighbour id: never dereference it
@@ -185,8 +275,6 @@ __device__ __forceinline__ void load_edge(const svnet_edgeblock_bwd_desc& d, int
     // clamped lane indices: every lane issues every load (no exec-masked branches, loads go out back to back);
     // lanes outside a channel range read a valid neighbour element that is masked where it is consumed
     const int ls = min(lane, Cs - 1), ld = min(lane, Cv - 1), lc = v2_lane ? cm : 0;
-    in.si = d.s[gp * Cs + ls];
-    in.sj = d.s[gj * Cs + ls];
     in.vi0 = d.v[(gp * 3 + 0) * Cv + lc];
     in.vi1 = d.v[(gp * 3 + 1) * Cv + lc];
     in.vi2 = d.v[(gp * 3 + 2) * Cv + lc];
@@ -198,42 +286,20 @@ __device__ __forceinline__ void load_edge(const svnet_edgeblock_bwd_desc& d, int
     in.z0 = zj[0] + (zi[3] - zi[0]);    in.z1 = zj[1] + (zi[4] - zi[1]);    in.z2 = zj[2] + (zi[5] - zi[2]);
     in.z3 = zj[6] + (zi[9] - zi[6]);    in.z4 = zj[7] + (zi[10] - zi[7]);   in.z5 = zj[8] + (zi[11] - zi[8]);
     in.z6 = zj[12] + (zi[15] - zi[12]); in.z7 = zj[13] + (zi[16] - zi[13]); in.z8 = zj[14] + (zi[17] - zi[14]);
-    if (want_u) {
-        const float* ui = d.ut + gp * 6 * Ov;
-        const float* uj = d.ut + gj * 6 * Ov;
-        const int lo = min(lane, Ov - 1);
-        in.ui0 = ui[0 * 2 * Ov + Ov + lo] - ui[0 * 2 * Ov + lo];
-        in.ui1 = ui[1 * 2 * Ov + Ov + lo] - ui[1 * 2 * Ov + lo];
-        in.ui2 = ui[2 * 2 * Ov + Ov + lo] - ui[2 * 2 * Ov + lo];
-        in.uj0 = uj[0 * 2 * Ov + lo];
-        in.uj1 = uj[1 * 2 * Ov + lo];
-        in.uj2 = uj[2 * 2 * Ov + lo];
-        // per-point operands of the edge math, fetched with the row so that nothing is loaded mid-computation
-        in.gv0 = d.gv[(gp * 3 + 0) * Ov + lo];
-        in.gv1 = d.gv[(gp * 3 + 1) * Ov + lo];
-        in.gv2 = d.gv[(gp * 3 + 2) * Ov + lo];
-        in.gt = d.gate[in.b * Ov + lo];
-        const int Os = d.Os;
-        const int o0 = min(lane, Os - 1), o1 = min(lane + 64, Os - 1);
-        in.gy0 = d.gy[gp * Os + o0];
-        in.gy1 = d.gy[gp * Os + o1];
-        in.slot0 = pos0 ? d.slot_max[gp * Os + o0] : d.slot_min[gp * Os + o0];
-        in.slot1 = pos1 ? d.slot_max[gp * Os + o1] : d.slot_min[gp * Os + o1];
-    } else {
-        in.gc0 = d.gconst[in.b * 2 * Cs + ls];
-        in.gc1 = d.gconst[in.b * 2 * Cs + Cs + ls];
-    }
+    in.gc0 = d.gconst[in.b * 2 * Cs + ls];
+    in.gc1 = d.gconst[in.b * 2 * Cs + Cs + ls];
 }
 
-template <int OP, int MODE>  // MODE: 0 = product; 1..3 = timing-only ablations (SVNET_BWD_MODE), wrong results
-__global__ __launch_bounds__(256, (OP == 1 ? 3 : 2)) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_desc d) {
+template <int MODE>  // MODE: 0 = product; 1..3 = timing-only ablations (SVNET_BWD_MODE), wrong results
+__global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_desc d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int Cs = d.Cs, Cv = d.Cv, Os = d.Os, Ov = d.Ov;
+    const int Cs = d.Cs, Cv = d.Cv, Os = d.Os;
     const int DNS = Os + 4;
     float* dxl = reinterpret_cast<float*>(smem);                    // [TE][DXS]   masked dx_b            (phases B -> C)
     float* dnl = dxl;                                                // [TE][DNS]   dL/dn = dy_pre*scale   (phases A -> B), ALIASES dxl:
                                                                      //             phase B pulls it into registers before writing dxl
     uint64_t* pl = reinterpret_cast<uint64_t*>(dxl + TE * DXS);      // [3][TE][NW] sign | nz | ste (row-major words)
+    float* chc = reinterpret_cast<float*>(pl + 3 * TE * NW);         // [5][Os]     per-channel constants of phase A
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // uniform: scalar loads / SGPR addressing
@@ -249,127 +315,61 @@ __global__ __launch_bounds__(256, (OP == 1 ? 3 : 2)) void edgeblock_bwd_kernel(s
     const int64_t e0 = tile * TE;
     const int64_t ew = e0 + wave * (TE / 4);                          // first edge row of this wave
 
-    const float* A1 = d.coef; const float* MY = d.coef + 2 * Os; const float* IY = d.coef + 3 * Os;
-    const float* Av = d.coef + 4 * Os; const float* Bv = Av + Ov;
-    const float* M1 = d.bcoef; const float* M2 = d.bcoef + Os; const float* CS = d.bcoef + 2 * Os;
-    const float* C0 = d.bcoef + 3 * Os; const float* C1 = C0 + Ov;
-
-    const bool s_lane = lane < Cs, v2_lane = lane < 2 * Cv, diff_lane = lane < Cv, o_lane = lane < Ov;
+    const bool s_lane = lane < Cs, v2_lane = lane < 2 * Cv, diff_lane = lane < Cv;
     const int cm = diff_lane ? lane : lane - Cv;
-    const float bd = d.beta_perm[lane], bc = d.beta_perm[64 + lane];
-    const float bv0 = d.beta_perm[128 + lane], bv1 = d.beta_perm[192 + lane], bv2 = d.beta_perm[256 + lane];
 
-    // ================= phase A =================
+    // ================= phase A: dL/dy_pre of the tile's 32 x Os edge-channels from the saved integer sums =========
+    //   dy_pre = cs*(g - m1 - xhat*m2), xhat = (scale*n - mean)*invstd, g = gy[p,o] on the pooled edge, else 0
+    //          = cs*g - (alpha + beta*n)
     {
-        uint64_t wsg[OP][NW], wnz[OP][NW];
-        float a1[OP], my[OP], iy[OP], m1[OP], m2[OP], cs[OP], sc1[OP];
-#pragma unroll
-        for (int op = 0; op < OP; ++op) {
-            const int o = lane + 64 * op;
-            const bool ok = o < Os;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                wsg[op][w] = ok ? d.w_sign[o * NW + w] : 0ull;
-                wnz[op][w] = ok ? d.w_nz[o * NW + w] : 0ull;
-            }
-            a1[op] = ok ? A1[o] : 0.f; my[op] = ok ? MY[o] : 0.f; iy[op] = ok ? IY[o] : 0.f;
-            m1[op] = ok ? M1[o] : 0.f; m2[op] = ok ? M2[o] : 0.f; cs[op] = ok ? CS[o] : 0.f; sc1[op] = ok ? d.scale1[o] : 0.f;
+        const float* A1 = d.coef; const float* MY = d.coef + 2 * Os; const float* IY = d.coef + 3 * Os;
+        const float* M1 = d.bcoef; const float* M2 = d.bcoef + Os; const float* CS = d.bcoef + 2 * Os;
+        for (int o = tid; o < Os; o += 256) {
+            const float cs = CS[o], sc = d.scale1[o], iy = IY[o];
+            chc[o] = cs;
+            chc[Os + o] = cs * (M1[o] - MY[o] * iy * M2[o]);     // alpha
+            chc[2 * Os + o] = cs * sc * iy * M2[o];               // beta
+            chc[3 * Os + o] = sc;
+            chc[4 * Os + o] = A1[o] >= 0.f ? 1.f : 0.f;           // the pooled edge is the arg-max (A1 >= 0) or the arg-min
         }
-        const float avc = o_lane ? Av[lane] : 0.f, bvc = o_lane ? Bv[lane] : 0.f;
-        const float c0 = o_lane ? C0[lane] : 0.f, c1 = o_lane ? C1[lane] : 0.f;
-        const float invk = 1.f / (float)d.k;
-
-        int64_t cur_p = -1;
-        float cv0 = 0.f, cv1 = 0.f, cv2 = 0.f;   // centre sum of dv' for the current point
-        EdgeIn in, nx;
-        load_edge(d, ew, E, lane, s_lane, v2_lane, diff_lane, o_lane, cm, true, a1[0] >= 0.f, a1[OP - 1] >= 0.f, in);
-#pragma unroll 1
-        for (int rr = 0; rr < TE / 4; ++rr) {
-            const int r = wave * (TE / 4) + rr;
-            // issue the NEXT edge's loads before this edge's atomics: vmcnt retires in order, so loads queued behind
-            // atomics would expose the full atomic latency on every edge
-            nx.valid = false;
-            if (rr + 1 < TE / 4) load_edge(d, ew + rr + 1, E, lane, s_lane, v2_lane, diff_lane, o_lane, cm, true, a1[0] >= 0.f, a1[OP - 1] >= 0.f, nx);
-            if (!in.valid) {  // wave-uniform: rows past the end (or corrupted ids) contribute zeros
-                for (int o = lane; o < Os; o += 64) dnl[r * DNS + o] = 0.f;
-                if (lane < NW) { pl[(0 * TE + r) * NW + lane] = 0ull; pl[(1 * TE + r) * NW + lane] = 0ull; pl[(2 * TE + r) * NW + lane] = 0ull; }
-                in = nx;
-                continue;
-            }
-            const int64_t e = ew + rr, gp = in.gp, gj = in.gj;
-            if (gp != cur_p) {
-                if (cur_p >= 0 && o_lane) {
-                    ATOMIC_ADD(&d.dvc[(cur_p * 3 + 0) * Ov + lane], cv0);
-                    ATOMIC_ADD(&d.dvc[(cur_p * 3 + 1) * Ov + lane], cv1);
-                    ATOMIC_ADD(&d.dvc[(cur_p * 3 + 2) * Ov + lane], cv2);
-                }
-                cur_p = gp;
-                cv0 = cv1 = cv2 = 0.f;
-            }
-            // ---- recompute the edge row (same arithmetic as edgeblock_fwd_kernel)
-            const float tc = in.si + bc;
-            const float td = (in.sj - in.si) + bd;
-            uint64_t xs[NW], xz[NW], xt[NW];
-            xs[1] = __ballot(s_lane && tc > 0.f); xz[1] = __ballot(s_lane && tc != 0.f); xt[1] = __ballot(s_lane && fabsf(tc) <= 1.2f);
-            xs[0] = __ballot(s_lane && td > 0.f); xz[0] = __ballot(s_lane && td != 0.f); xt[0] = __ballot(s_lane && fabsf(td) <= 1.2f);
-            const float ve0 = diff_lane ? (in.vj0 - in.vi0) : (v2_lane ? in.vi0 : 0.f);
-            const float ve1 = diff_lane ? (in.vj1 - in.vi1) : (v2_lane ? in.vi1 : 0.f);
-            const float ve2 = diff_lane ? (in.vj2 - in.vi2) : (v2_lane ? in.vi2 : 0.f);
-            const float tv0 = ve0 * in.z0 + ve1 * in.z3 + ve2 * in.z6 + bv0;
-            const float tv1 = ve0 * in.z1 + ve1 * in.z4 + ve2 * in.z7 + bv1;
-            const float tv2 = ve0 * in.z2 + ve1 * in.z5 + ve2 * in.z8 + bv2;
-            xs[2] = __ballot(v2_lane && tv0 > 0.f); xz[2] = __ballot(v2_lane && tv0 != 0.f); xt[2] = __ballot(v2_lane && fabsf(tv0) <= 1.2f);
-            xs[3] = __ballot(v2_lane && tv1 > 0.f); xz[3] = __ballot(v2_lane && tv1 != 0.f); xt[3] = __ballot(v2_lane && fabsf(tv1) <= 1.2f);
-            xs[4] = __ballot(v2_lane && tv2 > 0.f); xz[4] = __ballot(v2_lane && tv2 != 0.f); xt[4] = __ballot(v2_lane && fabsf(tv2) <= 1.2f);
-            if (lane < NW) {
-                uint64_t a = xs[0], bq = xz[0], cq = xt[0];
-#pragma unroll
-                for (int w = 1; w < NW; ++w) {
-                    if (lane == w) { a = xs[w]; bq = xz[w]; cq = xt[w]; }
-                }
-                pl[(0 * TE + r) * NW + lane] = a;
-                pl[(1 * TE + r) * NW + lane] = bq;
-                pl[(2 * TE + r) * NW + lane] = cq;
-            }
-            // ---- scalar path: n, dL/dy_pre
-#pragma unroll
-            for (int op = 0; op < OP; ++op) {
-                const int o = lane + 64 * op;
-                if (o < Os) {
-                    int n = 0;
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) n += tdot(xs[w], xz[w], wsg[op][w], wnz[op][w]);
-                    const int slot = op == 0 ? in.slot0 : in.slot1;
-                    const float g = (slot == in.t) ? (op == 0 ? in.gy0 : in.gy1) : 0.f;
-                    const float xh = (sc1[op] * (float)n - my[op]) * iy[op];
-                    const float dyp = cs[op] * (g - m1[op] - xh * m2[op]);
-                    d.dn_out[e * Os + o] = dyp;
-                    dnl[r * DNS + o] = dyp * sc1[op];
-                }
-            }
-            // ---- vector path: v' = U_j - U_i + T_i, out = gate * mean_k v'*(Av + Bv/n')
-            if (o_lane) {
-                const float gt = in.gt * invk;
-                const float vp0 = in.uj0 + in.ui0, vp1 = in.uj1 + in.ui1, vp2 = in.uj2 + in.ui2;
-                const float ge0 = in.gv0 * gt, ge1 = in.gv1 * gt, ge2 = in.gv2 * gt;
-                const float nv = sqrtf(vp0 * vp0 + vp1 * vp1 + vp2 * vp2);
-                const float nn = nv + VEPS;
-                const float q = avc + bvc / nn;
-                const float gdot = ge0 * vp0 + ge1 * vp1 + ge2 * vp2;
-                const float dnn = -gdot * bvc / (nn * nn) + c0 + c1 * nn;
-                const float kk = nv > 0.f ? dnn / nv : 0.f;
-                const float d0 = ge0 * q + kk * vp0, d1 = ge1 * q + kk * vp1, d2 = ge2 * q + kk * vp2;
-                ATOMIC_ADD(&d.du_acc[(gj * 3 + 0) * Ov + lane], d0);
-                ATOMIC_ADD(&d.du_acc[(gj * 3 + 1) * Ov + lane], d1);
-                ATOMIC_ADD(&d.du_acc[(gj * 3 + 2) * Ov + lane], d2);
-                cv0 += d0; cv1 += d1; cv2 += d2;
-            }
-            in = nx;
+        // ternary / STE planes of the tile: [e][plane][word] in HBM -> [plane][row][word] in LDS
+        for (int item = tid; item < TE * 3 * NW; item += 256) {
+            const int r = item / (3 * NW), q = item - r * (3 * NW);
+            const int plane = q / NW, w = q - plane * NW;
+            pl[(plane * TE + r) * NW + w] = (e0 + r < E) ? d.planes[(e0 + r) * (3 * NW) + q] : 0ull;
         }
-        if (cur_p >= 0 && o_lane) {
-            ATOMIC_ADD(&d.dvc[(cur_p * 3 + 0) * Ov + lane], cv0);
-            ATOMIC_ADD(&d.dvc[(cur_p * 3 + 1) * Ov + lane], cv1);
-            ATOMIC_ADD(&d.dvc[(cur_p * 3 + 2) * Ov + lane], cv2);
+        __syncthreads();
+        const int O4 = Os >> 2;
+        const int k = (int)d.k;
+        for (int item = tid; item < TE * O4; item += 256) {
+            const int r = item / O4, o4 = (item - r * O4) << 2;
+            const int64_t e = e0 + r;
+            float4 dn = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < E) {
+                const int64_t gp = e / k;
+                const int t = (int)(e - gp * k);
+                const short4 n4 = *reinterpret_cast<const short4*>(d.n16 + e * Os + o4);
+                const float4 gy4 = *reinterpret_cast<const float4*>(d.gy + gp * Os + o4);
+                const uchar4 smx = *reinterpret_cast<const uchar4*>(d.slot_max + gp * Os + o4);
+                const uchar4 smn = *reinterpret_cast<const uchar4*>(d.slot_min + gp * Os + o4);
+                const float4 cs = *reinterpret_cast<const float4*>(chc + o4);
+                const float4 al = *reinterpret_cast<const float4*>(chc + Os + o4);
+                const float4 be = *reinterpret_cast<const float4*>(chc + 2 * Os + o4);
+                const float4 sc = *reinterpret_cast<const float4*>(chc + 3 * Os + o4);
+                const float4 ps = *reinterpret_cast<const float4*>(chc + 4 * Os + o4);
+                const float g0 = ((ps.x != 0.f ? smx.x : smn.x) == t) ? gy4.x : 0.f;
+                const float g1 = ((ps.y != 0.f ? smx.y : smn.y) == t) ? gy4.y : 0.f;
+                const float g2 = ((ps.z != 0.f ? smx.z : smn.z) == t) ? gy4.z : 0.f;
+                const float g3 = ((ps.w != 0.f ? smx.w : smn.w) == t) ? gy4.w : 0.f;
+                float4 dy;
+                dy.x = cs.x * g0 - (al.x + be.x * (float)n4.x);
+                dy.y = cs.y * g1 - (al.y + be.y * (float)n4.y);
+                dy.z = cs.z * g2 - (al.z + be.z * (float)n4.z);
+                dy.w = cs.w * g3 - (al.w + be.w * (float)n4.w);
+                *reinterpret_cast<float4*>(d.dn_out + e * Os + o4) = dy;
+                dn = make_float4(dy.x * sc.x, dy.y * sc.y, dy.z * sc.z, dy.w * sc.w);
+            }
+            *reinterpret_cast<float4*>(dnl + r * DNS + o4) = dn;
         }
     }
     __syncthreads();
@@ -482,12 +482,12 @@ __global__ __launch_bounds__(256, (OP == 1 ? 3 : 2)) void edgeblock_bwd_kernel(s
     } while (0)
 
         EdgeIn in, nx;
-        load_edge(d, ew, E, lane, s_lane, v2_lane, diff_lane, o_lane, cm, false, false, false, in);
+        load_edge(d, ew, E, lane, v2_lane, cm, in);
 #pragma unroll 1
         for (int rr = 0; rr < TE / 4; ++rr) {
             const int r = wave * (TE / 4) + rr;
             nx.valid = false;
-            if (rr + 1 < TE / 4) load_edge(d, ew + rr + 1, E, lane, s_lane, v2_lane, diff_lane, o_lane, cm, false, false, false, nx);
+            if (rr + 1 < TE / 4) load_edge(d, ew + rr + 1, E, lane, v2_lane, cm, nx);
             if (!in.valid) { in = nx; continue; }
             const int64_t gp = in.gp, gj = in.gj;
             if (gp != cur_p) {
@@ -601,24 +601,36 @@ extern "C" int svnet_edgeblock_bwd_coeffs_f32(const float* red, const float* red
 extern "C" int svnet_edgeblock_bwd_f32(const svnet_edgeblock_bwd_desc* desc, void* stream) {
     SVNET_REQUIRE(desc, SVNET_E_ARG, "svnet_edgeblock_bwd_f32: null descriptor");
     const svnet_edgeblock_bwd_desc& d = *desc;
-    SVNET_REQUIRE(d.s && d.v && d.idx && d.zz && d.ut && d.w_sign && d.w_nz && d.beta_perm && d.w1bt && d.scale1 && d.slot_max &&
-                      d.slot_min && d.coef && d.gate && d.gy && d.bcoef && d.gv && d.gconst && d.dn_out && d.x_sign32 && d.x_nz32 &&
-                      d.ds_acc && d.dv_acc && d.du_acc && d.dvc && d.dzp_acc && d.dzc && d.dbeta_perm,
+    SVNET_REQUIRE(d.v && d.idx && d.zz && d.ut && d.n16 && d.planes && d.w1bt && d.scale1 && d.slot_max && d.slot_min && d.coef &&
+                      d.gate && d.gy && d.bcoef && d.gv && d.gconst && d.dn_out && d.x_sign32 && d.x_nz32 && d.ds_acc && d.dv_acc &&
+                      d.du_acc && d.dvc && d.dzp_acc && d.dzc && d.dbeta_perm,
                   SVNET_E_ARG, "svnet_edgeblock_bwd_f32: null pointer");
     SVNET_REQUIRE(d.B >= 0 && d.N > 0 && d.k > 0 && d.k <= 255, SVNET_E_ARG, "svnet_edgeblock_bwd_f32: bad sizes");
     SVNET_REQUIRE(d.Cs > 0 && d.Cs <= 64 && d.Cv > 0 && 2 * d.Cv <= 64 && d.Os > 0 && d.Os <= 128 && d.Os % 8 == 0 && d.Ov > 0 &&
                       d.Ov <= 64, SVNET_E_UNSUPPORTED, "svnet_edgeblock_bwd_f32: channel counts outside Cs<=64, 2Cv<=64, Os<=128 (mult of 8), Ov<=64");
     const int64_t E = d.B * d.N * d.k;
     if (E == 0) return SVNET_OK;
-    const size_t lds = (size_t)TE * DXS * 4 + (size_t)3 * TE * NW * 8;   // dnl aliases dxl
-    const unsigned grid = (unsigned)svnet_cdiv(E, TE);
+    hipStream_t st = (hipStream_t)stream;
     static const int mode = getenv("SVNET_BWD_MODE") ? atoi(getenv("SVNET_BWD_MODE")) : 0;
-#define SVNET_LAUNCH_BWD(OP, MODE) hipLaunchKernelGGL((edgeblock_bwd_kernel<OP, MODE>), dim3(grid), dim3(256), lds, (hipStream_t)stream, d)
-    if (d.Os <= 64) {
-        if (mode == 1) SVNET_LAUNCH_BWD(1, 1); else if (mode == 2) SVNET_LAUNCH_BWD(1, 2); else if (mode == 3) SVNET_LAUNCH_BWD(1, 3); else SVNET_LAUNCH_BWD(1, 0);
-    } else {
-        if (mode == 1) SVNET_LAUNCH_BWD(2, 1); else if (mode == 2) SVNET_LAUNCH_BWD(2, 2); else if (mode == 3) SVNET_LAUNCH_BWD(2, 3); else SVNET_LAUNCH_BWD(2, 0);
-    }
+
+    // vector path: wave per point
+    VecArgs va;
+    va.d = d;
+    int wpc = (int)svnet_cdiv(4096, d.B);                 // ~4096 waves in flight (16 per CU)
+    if (wpc > d.N) wpc = (int)d.N;
+    if (wpc < 1) wpc = 1;
+    va.points_per_wave = (int)svnet_cdiv(d.N, wpc);
+    va.waves_per_cloud = (int)svnet_cdiv(d.N, va.points_per_wave);
+    const unsigned vgrid = (unsigned)svnet_cdiv(d.B * va.waves_per_cloud, 4);
+    if (mode == 1) hipLaunchKernelGGL((edgeblock_bwd_vec_kernel<1>), dim3(vgrid), dim3(256), 0, st, va);
+    else hipLaunchKernelGGL((edgeblock_bwd_vec_kernel<0>), dim3(vgrid), dim3(256), 0, st, va);
+    SVNET_CHECK_LAUNCH("edgeblock_bwd_vec_kernel");
+
+    // scalar path: 32-edge tiles
+    const size_t lds = (size_t)TE * DXS * 4 + (size_t)3 * TE * NW * 8 + (size_t)5 * d.Os * 4;   // dnl aliases dxl
+    const unsigned grid = (unsigned)svnet_cdiv(E, TE);
+#define SVNET_LAUNCH_BWD(MODE) hipLaunchKernelGGL((edgeblock_bwd_kernel<MODE>), dim3(grid), dim3(256), lds, st, d)
+    if (mode == 1) SVNET_LAUNCH_BWD(1); else if (mode == 2) SVNET_LAUNCH_BWD(2); else if (mode == 3) SVNET_LAUNCH_BWD(3); else SVNET_LAUNCH_BWD(0);
 #undef SVNET_LAUNCH_BWD
     SVNET_CHECK_LAUNCH("edgeblock_bwd_kernel");
     return SVNET_OK;

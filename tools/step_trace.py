@@ -1,0 +1,25 @@
+"""Print the ordered kernel sequence of the last full step from a rocprofv3 kernel trace CSV (diagnostic)."""
+import csv, re, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+names = [r['Kernel_Name'] for r in rows]
+idxs = [i for i, n in enumerate(names) if 'smooth_ce' in n and 'bwd' not in n]
+a, b = idxs[-2], idxs[-1]
+def short(n):
+    n = re.sub(r'void |at::native::|\(anonymous namespace\)::', '', n)
+    n = re.sub(r'vectorized_elementwise_kernel<\d, ', 'VE:', n)
+    n = re.sub(r'elementwise_kernel_manual_unroll<128, 4, gpu_kernel_impl_nocast<', 'EMU:', n)
+    n = re.sub(r'std::array.*', '', n)
+    n = re.sub(r'\(.*', '', n)
+    return n[:50]
+tot = collections.Counter(); cnt = collections.Counter()
+t0 = int(rows[a]['Start_Timestamp'])
+for i in range(a, b):
+    r = rows[i]
+    d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1000
+    tot[short(names[i])] += d; cnt[short(names[i])] += 1
+    if len(sys.argv) > 2:
+        print(i - a, short(names[i]), round(d, 1), round((int(r['Start_Timestamp']) - t0) / 1000, 1))
+print("kernels/step", b - a, "sum us", round(sum(tot.values()), 1), "span us", (int(rows[b]['Start_Timestamp']) - t0) / 1000)
+for n, t in tot.most_common(40):
+    print("%-52s %4d %9.1f" % (n, cnt[n], t))
