@@ -53,6 +53,46 @@ __device__ __forceinline__ void split3_frag(const float (&x)[8], bf16x8& fh, bf1
     }
 }
 
+// ---- cross-lane sums without the LDS crossbar (DPP modifiers + the gfx950 half / row swaps)
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_get(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+constexpr int DPP_QUAD_1032 = 0xB1, DPP_QUAD_2301 = 0x4E, DPP_ROW_ROR8 = 0x128, DPP_ROW_MIRROR = 0x140, DPP_ROW_HALF_MIRROR = 0x141,
+              DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+// sum over the wave of a (lanes 0..31 of the result) and of b (lanes 32..63), each still spread over its 32 lanes
+__device__ __forceinline__ float fold32(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// rows (16 lanes) 0..3 of the result: a.row0+a.row1 | b.row0+b.row1 | a.row2+a.row3 | b.row2+b.row3
+__device__ __forceinline__ float fold16(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// Eight wave-wide sums in 18 VALU instructions: every lane of the 8-lane group g = lane >> 3 ends up with the sum over the
+// wave of s[bitreverse3(g)]  (groups 0..7 hold s0, s4, s2, s6, s1, s5, s3, s7).
+__device__ __forceinline__ float wave_sum8_packed(const float (&s)[8], int lane) {
+    const float x0 = fold16(fold32(s[0], s[1]), fold32(s[2], s[3]));   // rows: s0 | s2 | s1 | s3
+    const float x1 = fold16(fold32(s[4], s[5]), fold32(s[6], s[7]));   // rows: s4 | s6 | s5 | s7
+    const bool hi = (lane & 8) != 0;
+    float y = (hi ? x1 : x0) + dpp_get<DPP_ROW_ROR8>(hi ? x0 : x1);
+    y += dpp_get<DPP_QUAD_1032>(y);
+    y += dpp_get<DPP_QUAD_2301>(y);
+    y += dpp_get<DPP_ROW_HALF_MIRROR>(y);
+    return y;
+}
+// wave-wide sum, valid in lane 63
+__device__ __forceinline__ float wave_sum_last(float v) {
+    v += dpp_get<DPP_QUAD_1032>(v);
+    v += dpp_get<DPP_QUAD_2301>(v);
+    v += dpp_get<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_get<DPP_ROW_MIRROR>(v);
+    v += dpp_get<DPP_ROW_BCAST15, 0xA>(v);
+    v += dpp_get<DPP_ROW_BCAST31, 0xC>(v);
+    return v;
+}
+
 // sign(W1) in fused column order as bf16 [NCOL][Os] (k = o contiguous: the MFMA B fragment is one 16-byte load)
 __global__ void edgeblock_wbt_kernel(const uint64_t* __restrict__ w_sign, const uint64_t* __restrict__ w_nz, int Os,
                                      uint16_t* __restrict__ wbt) {
@@ -461,7 +501,9 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
         int64_t cur_p = -1;
         float csum = 0.f;                           // centre part of ds for the current point (lane c < Cs)
         float cvd0 = 0.f, cvd1 = 0.f, cvd2 = 0.f;   // centre part of dv (diff lanes carry -sum, centre lanes +sum)
-        float czq0 = 0.f, czq1 = 0.f, czq2 = 0.f, czq3 = 0.f, czq4 = 0.f, czq5 = 0.f, czq6 = 0.f, czq7 = 0.f, czq8 = 0.f;
+        float czq = 0.f, czq8 = 0.f;                // centre sums of dL/dz: packed (group g of 8 lanes: entry bitreverse3(g)), entry 8
+        const int zq_idx = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2);   // bitreverse3(lane >> 3)
+        const bool zq_writer = (lane & 7) == 0;
 
 // (a macro: a by-reference lambda forces the per-point accumulators into scratch memory)
 #define SVNET_FLUSH_POINT(p)                                                                                      \
@@ -472,13 +514,8 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
             ATOMIC_ADD(&d.dv_acc[((p) * 3 + 1) * Cv + cm], cvd1);                                                  \
             ATOMIC_ADD(&d.dv_acc[((p) * 3 + 2) * Cv + cm], cvd2);                                                  \
         }                                                                                                         \
-        if (lane < 9) {                                                                                           \
-            float val_ = czq0;                                                                                    \
-            val_ = (lane == 1) ? czq1 : val_; val_ = (lane == 2) ? czq2 : val_; val_ = (lane == 3) ? czq3 : val_; \
-            val_ = (lane == 4) ? czq4 : val_; val_ = (lane == 5) ? czq5 : val_; val_ = (lane == 6) ? czq6 : val_; \
-            val_ = (lane == 7) ? czq7 : val_; val_ = (lane == 8) ? czq8 : val_;                                   \
-            ATOMIC_ADD(&d.dzc[(p) * 9 + lane], val_);                                                              \
-        }                                                                                                         \
+        if (zq_writer) ATOMIC_ADD(&d.dzc[(p) * 9 + zq_idx], czq);                                                  \
+        if (lane == 63) ATOMIC_ADD(&d.dzc[(p) * 9 + 8], czq8);                                                     \
     } while (0)
 
         EdgeIn in, nx;
@@ -495,7 +532,7 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
                 cur_p = gp;
                 csum = 0.f;
                 cvd0 = cvd1 = cvd2 = 0.f;
-                czq0 = czq1 = czq2 = czq3 = czq4 = czq5 = czq6 = czq7 = czq8 = 0.f;
+                czq = czq8 = 0.f;
             }
             const float* row = dxl + r * DXS;
             const float gx0 = s_lane ? row[lane] : 0.f;            // d/d(s_j - s_i) through the binarization
@@ -512,10 +549,12 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
             const float dve0 = g0 * in.z0 + g1 * in.z1 + g2 * in.z2;
             const float dve1 = g0 * in.z3 + g1 * in.z4 + g2 * in.z5;
             const float dve2 = g0 * in.z6 + g1 * in.z7 + g2 * in.z8;
-            const float dz0 = wave_sum(g0 * ve0), dz1 = wave_sum(g1 * ve0), dz2 = wave_sum(g2 * ve0);
-            const float dz3 = wave_sum(g0 * ve1), dz4 = wave_sum(g1 * ve1), dz5 = wave_sum(g2 * ve1);
-            const float dz6 = wave_sum(g0 * ve2), dz7 = wave_sum(g1 * ve2), dz8 = wave_sum(g2 * ve2);
-            czq0 += dz0; czq1 += dz1; czq2 += dz2; czq3 += dz3; czq4 += dz4; czq5 += dz5; czq6 += dz6; czq7 += dz7; czq8 += dz8;
+            // dL/dz[d][jz] = sum over the lanes of g_jz * ve_d: nine wave-wide sums, eight of them packed
+            const float pz[8] = {g0 * ve0, g1 * ve0, g2 * ve0, g0 * ve1, g1 * ve1, g2 * ve1, g0 * ve2, g1 * ve2};
+            const float dzp = wave_sum8_packed(pz, lane);
+            const float dz8 = wave_sum_last(g2 * ve2);
+            czq += dzp;
+            czq8 += dz8;
             if (diff_lane) { cvd0 -= dve0; cvd1 -= dve1; cvd2 -= dve2; }
             else if (v2_lane) { cvd0 += dve0; cvd1 += dve1; cvd2 += dve2; }
             // ---- scatter to the neighbour's rows (one contiguous segment per wave-instruction)
@@ -525,13 +564,8 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
                 ATOMIC_ADD(&d.dv_acc[(gj * 3 + 1) * Cv + lane], dve1);
                 ATOMIC_ADD(&d.dv_acc[(gj * 3 + 2) * Cv + lane], dve2);
             }
-            if (lane < 9) {
-                float val = dz0;
-                val = (lane == 1) ? dz1 : val; val = (lane == 2) ? dz2 : val; val = (lane == 3) ? dz3 : val;
-                val = (lane == 4) ? dz4 : val; val = (lane == 5) ? dz5 : val; val = (lane == 6) ? dz6 : val;
-                val = (lane == 7) ? dz7 : val; val = (lane == 8) ? dz8 : val;
-                ATOMIC_ADD(&d.dzp_acc[gj * 9 + lane], val);
-            }
+            if (zq_writer) ATOMIC_ADD(&d.dzp_acc[gj * 9 + zq_idx], dzp);
+            if (lane == 63) ATOMIC_ADD(&d.dzp_acc[gj * 9 + 8], dz8);
             in = nx;
         }
         if (cur_p >= 0) SVNET_FLUSH_POINT(cur_p);
