@@ -72,7 +72,7 @@ constexpr int LDS_STRIDE = KC + 8;  // bf16 elements per LDS row: (KC/8 + 1) 16-
 
 // NT = number of 32-column tiles handled by a workgroup (N_tile = 32*NT <= 256); 4 waves x 32 rows per iteration.
 template <int NT>
-__global__ __launch_bounds__(256) void mfma_rows_kernel(RowsArgs a) {
+__global__ __launch_bounds__(256, 2) void mfma_rows_kernel(RowsArgs a) {
     extern __shared__ __attribute__((aligned(16))) __bf16 Bt[];  // [NT*32][LDS_STRIDE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -89,11 +89,28 @@ __global__ __launch_bounds__(256) void mfma_rows_kernel(RowsArgs a) {
         const int64_t m0 = rb * 128 + wave * 32;
         const int64_t arow = m0 + r;
         const bool row_ok = arow < a.M;
+        const float* arp = a.A + (row_ok ? arow : 0) * a.lda;     // rows past the end read row 0 and are never stored
         f32x16 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+        // one A fragment (8 consecutive k of my row) ahead of the MFMAs that consume it
+        float xn[8];
+#define SVNET_LOAD_A(KK)                                                                                      \
+    do {                                                                                                      \
+        const int kk_ = (KK);                                                                                 \
+        if (a.a_vec && kk_ + 8 <= a.K) {                                                                      \
+            const float4 v0_ = *reinterpret_cast<const float4*>(arp + kk_);                                   \
+            const float4 v1_ = *reinterpret_cast<const float4*>(arp + kk_ + 4);                               \
+            xn[0] = v0_.x; xn[1] = v0_.y; xn[2] = v0_.z; xn[3] = v0_.w;                                       \
+            xn[4] = v1_.x; xn[5] = v1_.y; xn[6] = v1_.z; xn[7] = v1_.w;                                       \
+        } else {                                                                                              \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) xn[j] = (kk_ + j < a.K) ? arp[kk_ + j] : 0.f;       \
+        }                                                                                                     \
+    } while (0)
+        SVNET_LOAD_A(8 * h);
 
         for (int ch = 0; ch < nchunks; ++ch) {
             const int k0 = ch * KC;
@@ -101,14 +118,33 @@ __global__ __launch_bounds__(256) void mfma_rows_kernel(RowsArgs a) {
             const int kc16 = (kc + 15) & ~15;
             if (nchunks > 1 || !b_loaded) {
                 __syncthreads();  // previous readers of Bt are done
-                const int total = NT * 32 * kc16;
-                const bool k_fast = (a.b_rs == 1);
-                for (int e = tid; e < total; e += 256) {
-                    int n, k;
-                    if (k_fast) { k = e % kc16; n = e / kc16; } else { n = e % (NT * 32); k = e / (NT * 32); }
-                    float v = 0.f;
-                    if (n0 + n < a.N && k < kc) v = a.B[(int64_t)(k0 + k) * a.b_rs + (int64_t)(n0 + n) * a.b_cs];
-                    Bt[n * LDS_STRIDE + k] = bf16_from_bits(__float_as_uint(v) >> 16);
+                // stage B[k0 : k0+kc, n0 : n0+NT*32] as bf16 [n][k]: one 16-byte LDS store per 8 consecutive k
+                const int pieces = NT * 32 * (kc16 >> 3);
+                if (a.b_rs == 1) {            // k contiguous in memory: consecutive threads walk k
+                    const int kp = kc16 >> 3;
+                    for (int e = tid; e < pieces; e += 256) {
+                        const int n = e / kp, k8 = (e - n * kp) << 3;
+                        bf16x8 pk;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            float v = 0.f;
+                            if (n0 + n < a.N && k8 + j < kc) v = a.B[(int64_t)(k0 + k8 + j) + (int64_t)(n0 + n) * a.b_cs];
+                            pk[j] = bf16_from_bits(__float_as_uint(v) >> 16);
+                        }
+                        *reinterpret_cast<bf16x8*>(&Bt[n * LDS_STRIDE + k8]) = pk;
+                    }
+                } else {                       // n contiguous (or general): consecutive threads walk n
+                    for (int e = tid; e < pieces; e += 256) {
+                        const int n = e % (NT * 32), k8 = (e / (NT * 32)) << 3;
+                        bf16x8 pk;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            float v = 0.f;
+                            if (n0 + n < a.N && k8 + j < kc) v = a.B[(int64_t)(k0 + k8 + j) * a.b_rs + (int64_t)(n0 + n) * a.b_cs];
+                            pk[j] = bf16_from_bits(__float_as_uint(v) >> 16);
+                        }
+                        *reinterpret_cast<bf16x8*>(&Bt[n * LDS_STRIDE + k8]) = pk;
+                    }
                 }
                 __syncthreads();
                 b_loaded = true;
@@ -116,14 +152,11 @@ __global__ __launch_bounds__(256) void mfma_rows_kernel(RowsArgs a) {
             for (int ks = 0; ks < kc16; ks += 16) {
                 float x[8];
                 const int kk = k0 + ks + 8 * h;
-                if (a.a_vec && row_ok && kk + 8 <= a.K) {
-                    const float4 v0 = *reinterpret_cast<const float4*>(a.A + arow * a.lda + kk);
-                    const float4 v1 = *reinterpret_cast<const float4*>(a.A + arow * a.lda + kk + 4);
-                    x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w;
-                    x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
-                } else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) x[j] = (row_ok && kk + j < a.K) ? a.A[arow * a.lda + kk + j] : 0.f;
+                for (int j = 0; j < 8; ++j) x[j] = xn[j];
+                {   // next fragment: next k-step of this chunk, or the first of the next chunk (none after the last)
+                    const int nk = (ks + 16 < kc16) ? kk + 16 : k0 + KC + 8 * h;
+                    if (nk < a.K) SVNET_LOAD_A(nk);
                 }
                 if (a.a_scale) {
 #pragma unroll
@@ -139,6 +172,7 @@ __global__ __launch_bounds__(256) void mfma_rows_kernel(RowsArgs a) {
                 }
             }
         }
+#undef SVNET_LOAD_A
         // ---- epilogue
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -189,7 +223,7 @@ struct TnArgs {
 // NQ 32-wide q tiles per workgroup (blockIdx.z picks the group).  The 4 waves cover `ptw` p tiles (1, 2 or 4 per
 // workgroup); when P is narrow (ptw < 4) the spare waves split the workgroup's row range instead of idling.
 template <int NQ, int BMODE>
-__global__ __launch_bounds__(256) void mfma_tn_kernel(TnArgs a) {
+__global__ __launch_bounds__(256, 2) void mfma_tn_kernel(TnArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int ptw = a.ptiles_per_block;                      // 1, 2 or 4
@@ -290,6 +324,129 @@ __global__ __launch_bounds__(256) void mfma_tn_kernel(TnArgs a) {
     }
 }
 
+// ---- tn with a TERNARY B operand (row-sliced planes): the weight-gradient product GX = x_b^T . dy of every binarized layer.
+// Same tiling as mfma_tn_kernel<NQ, 1>, but (a) the 8-row slices of the planes are expanded to bf16 fragments through two
+// 256-entry LDS tables (magnitude from the non-zero byte, sign bit from the negative byte) instead of 48 VALU operations
+// per fragment, (b) the A fragment of the next k-step and the plane words of the next 64-row block are loaded before the
+// MFMAs of the current one, (c) <= 256 VGPRs so that two waves per SIMD overlap each other's loads.
+template <int NQ>
+__global__ __launch_bounds__(256, 2) void mfma_tn_tern_kernel(TnArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t lut_mag[256 * 4], lut_neg[256 * 4];   // bf16x8 per byte value
+    {
+        const int b = threadIdx.x;   // 256 threads: one table row each
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t lo = (b >> (2 * w)) & 1u, hi = (b >> (2 * w + 1)) & 1u;
+            lut_mag[b * 4 + w] = lo * 0x3F80u | hi * 0x3F800000u;
+            lut_neg[b * 4 + w] = lo * 0x8000u | hi * 0x80000000u;
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int ptw = a.ptiles_per_block;                      // 1, 2 or 4
+    const int p0 = (blockIdx.y * ptw + (wave % ptw)) * 32;
+    const int q0 = blockIdx.z * (NQ * 32);
+    const bool live = p0 < a.P;                              // wave-uniform
+    const int nsub = 4 / ptw, sub = wave / ptw;
+    const int64_t rows_sub = ((a.rows_per_block / nsub + 63) >> 6) << 6;   // multiple of 64
+    const int64_t mb = (int64_t)blockIdx.x * a.rows_per_block + (int64_t)sub * rows_sub;
+    const int64_t me = min(min(a.M, (int64_t)(blockIdx.x + 1) * a.rows_per_block), mb + rows_sub);
+    const int p = min(p0 + r, a.P - 1);                      // clamped: columns past P are computed and never stored
+
+    f32x16 acc[NQ];
+#pragma unroll
+    for (int t = 0; t < NQ; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    if (live && mb < me) {
+        const int64_t mlast = a.M - 1;
+        uint64_t wsg[NQ], wnz[NQ], nsg[NQ], nnz[NQ];
+        float xn[8];
+#define SVNET_TN_WORDS(M64, SG, NZ)                                                      \
+    do {                                                                                 \
+        _Pragma("unroll") for (int t = 0; t < NQ; ++t) {                                 \
+            const int q_ = min(q0 + t * 32 + r, a.Q - 1);                                \
+            SG[t] = a.b_sign[((M64) >> 6) * a.Q + q_];                                   \
+            NZ[t] = a.b_nz[((M64) >> 6) * a.Q + q_];                                     \
+        }                                                                                \
+    } while (0)
+// rows past M read the last row; their plane bits are 0 (written so by the producers), so they contribute nothing
+#define SVNET_TN_LOAD_A(MROW)                                                            \
+    do {                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) xn[j] = a.A[min((MROW) + j, mlast) * a.lda + p]; \
+    } while (0)
+        constexpr bool PFW = NQ <= 5;   // plane words of the next block in flight too (register budget permitting)
+        if (PFW) SVNET_TN_WORDS(mb, nsg, nnz);
+        SVNET_TN_LOAD_A(mb + 8 * h);
+        for (int64_t m64 = mb; m64 < me; m64 += 64) {
+            if (PFW) {
+#pragma unroll
+                for (int t = 0; t < NQ; ++t) { wsg[t] = nsg[t]; wnz[t] = nnz[t]; }
+                if (m64 + 64 < me) SVNET_TN_WORDS(m64 + 64, nsg, nnz);
+            } else {
+                SVNET_TN_WORDS(m64, wsg, wnz);
+            }
+#pragma unroll
+            for (int s16 = 0; s16 < 64; s16 += 16) {
+                if (m64 + s16 >= me) break;  // wave-uniform
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = (m64 + s16 + 8 * h + j < me) ? xn[j] : 0.f;   // rows of the next sub-range are not mine
+                if (m64 + s16 + 16 < me) SVNET_TN_LOAD_A(m64 + s16 + 16 + 8 * h);
+                const Split3 sa = split_frag(x);
+                const int sh = s16 + 8 * h;
+#pragma unroll
+                for (int t = 0; t < NQ; ++t) {
+                    if (q0 + t * 32 >= a.Q) break;  // uniform
+                    const uint32_t nzb = (uint32_t)(wnz[t] >> sh) & 0xFFu;
+                    const uint32_t ngb = nzb & ~(uint32_t)(wsg[t] >> sh);
+                    const uint4 mg = *reinterpret_cast<const uint4*>(&lut_mag[nzb * 4]);
+                    const uint4 ng = *reinterpret_cast<const uint4*>(&lut_neg[ngb * 4]);
+                    const uint4 bw = make_uint4(mg.x | ng.x, mg.y | ng.y, mg.z | ng.z, mg.w | ng.w);
+                    const bf16x8 b = __builtin_bit_cast(bf16x8, bw);
+                    acc[t] = MFMA(sa.h, b, acc[t]);
+                    acc[t] = MFMA(sa.m, b, acc[t]);
+                    acc[t] = MFMA(sa.l, b, acc[t]);
+                }
+            }
+        }
+#undef SVNET_TN_WORDS
+#undef SVNET_TN_LOAD_A
+    }
+    // Waves that split the row range of one p tile (narrow P) first combine their partial tiles in LDS: the output
+    // matrix is tiny and shared by the whole grid, and same-address float atomics serialise at the memory side.
+    if (a.lds_reduce) {   // uniform; every wave of the workgroup is live in this configuration
+        extern __shared__ float tnred[];                     // [nsub-1][NQ][16][64]
+        if (sub > 0) {
+#pragma unroll
+            for (int t = 0; t < NQ; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tnred[(((sub - 1) * ptw + (wave % ptw)) * NQ + t) * 1024 + i * 64 + lane] = acc[t][i];
+        }
+        __syncthreads();
+        if (sub > 0) return;
+        for (int s2 = 1; s2 < nsub; ++s2)
+#pragma unroll
+            for (int t = 0; t < NQ; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[t][i] += tnred[(((s2 - 1) * ptw + (wave % ptw)) * NQ + t) * 1024 + i * 64 + lane];
+    }
+    if (!live) return;
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+        const int q = q0 + t * 32 + r;  // D col = lane & 31  <-> B operand column (q)
+        if (q < a.Q) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int pp = p0 + (i & 3) + 8 * (i >> 2) + 4 * h;  // D row <-> A operand row (p)
+                if (pp < a.P) atomicAdd(&a.C[(int64_t)pp * a.c_ps + (int64_t)q * a.c_qs], acc[t][i] * a.alpha);
+            }
+        }
+    }
+}
+
 __global__ void zero2d_kernel(float* C, int64_t P, int64_t Q, int64_t ps, int64_t qs) {
     const int64_t total = P * Q;
     for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x)
@@ -325,7 +482,17 @@ void launch_tn(TnArgs a, hipStream_t st) {
     const int nsub = 4 / a.ptiles_per_block;
     const size_t lds = (size_t)(nsub - 1) * a.ptiles_per_block * NQ * 1024 * sizeof(float);
     a.lds_reduce = (nsub > 1 && ptiles == a.ptiles_per_block && lds <= 64 * 1024) ? 1 : 0;
-    hipLaunchKernelGGL((mfma_tn_kernel<NQ, BMODE>), dim3((unsigned)gx, (unsigned)gy, (unsigned)gz), dim3(256), a.lds_reduce ? lds : 0, st, a);
+    if (BMODE == 1) {
+        static bool attr_set = false;   // 8 KiB of static tables + up to 64 KiB of dynamic LDS: above the 64 KiB default
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_tn_tern_kernel<NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            attr_set = true;
+        }
+    }
+    if (BMODE == 1)
+        hipLaunchKernelGGL((mfma_tn_tern_kernel<NQ>), dim3((unsigned)gx, (unsigned)gy, (unsigned)gz), dim3(256), a.lds_reduce ? lds : 0, st, a);
+    else
+        hipLaunchKernelGGL((mfma_tn_kernel<NQ, 0>), dim3((unsigned)gx, (unsigned)gy, (unsigned)gz), dim3(256), a.lds_reduce ? lds : 0, st, a);
 }
 
 }  // namespace
