@@ -161,9 +161,9 @@ int svnet_edgeblock_apply_f32(const int32_t* n_max, const int32_t* n_min, const 
  * (csrc/edgeblock_bwd.hip).  Outputs of svnet_edgeblock_bwd_f32 (caller zero-fills every *_acc, dzc, dbeta_perm):
  *   dn_out [E,Os]            dL/d(scale*n) per edge          -> GX = dn_out^T . x_b via svnet_gemm_f32 (ternary A)
  *   x_sign32/x_nz32          row-sliced planes of x_b in fused column order, [ceil(E/64), 320] uint64 viewed as uint32
- *   ds_acc [P,Cs], dv_acc [P,3,Cv]   gradients of the point tables (binarized + gate + v2s paths)
- *   du_acc/dvc [P,3,Ov]      neighbour / centre sums of dL/dv'   (dU = du_acc - dvc, dT = dvc)
- *   dzp_acc/dzc [P,3,3]      neighbour / centre sums of dL/dz    (dZp = dzp_acc - dzc, dZq = dzc)
+ *   msg [E,R]                per-edge contributions to the NEIGHBOUR j of each edge (summed by svnet_edgeblock_bwd_gather_f32)
+ *   ds_acc [P,Cs], dv_acc [P,3,Cv]   centre parts of the gradients of the point tables
+ *   dvc [P,3,Ov], dzc [P,3,3]  centre sums of dL/dv' and dL/dz   (dU = sum_j - dvc, dT = dvc; dZp = sum_j - dzc, dZq = dzc)
  *   dbeta_perm [320]         dL/dbeta in fused column order                                                      */
 typedef struct svnet_edgeblock_bwd_desc {
     int64_t B, N, k;
@@ -180,7 +180,8 @@ typedef struct svnet_edgeblock_bwd_desc {
     const float* gv;             /* upstream gradient of v_out [P,3,Ov] */
     const float* gconst;         /* [B,2Cs]: dL/d(gate input) / (N*k) */
     float* dn_out; uint32_t* x_sign32; uint32_t* x_nz32;
-    float* ds_acc; float* dv_acc; float* du_acc; float* dvc; float* dzp_acc; float* dzc; float* dbeta_perm;
+    float* msg;                  /* [E, svnet_edgeblock_msg_stride]: per-edge neighbour contributions (written, not accumulated) */
+    float* ds_acc; float* dv_acc; float* dvc; float* dzc; float* dbeta_perm;   /* centre sums (atomics) / dvc written */
     int64_t* debug;              /* optional [4]: {count, first bad edge, its idx value, N}; edges with idx outside [0,N) are skipped */
 } svnet_edgeblock_bwd_desc;
 int svnet_edgeblock_wbt_bf16(const uint64_t* w_sign, const uint64_t* w_nz, int64_t Os, uint16_t* wbt, void* stream);
@@ -194,11 +195,19 @@ int svnet_edgeblock_bwd_coeffs_f32(const float* red, const float* redv, const fl
                                    const float* gamma2, int64_t E, int64_t Os, int64_t Ov, int training, float* bcoef,
                                    float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, void* stream);
 int svnet_edgeblock_bwd_f32(const svnet_edgeblock_bwd_desc* desc, void* stream);
-/* After the edge pass: acat [3P, 2Ov+6] = [du_acc - dvc | dvc | dzp_acc - dzc | dzc] (the gradient of [U|T|Zp|Zq], so that
- * dv += (acat*scv) . wv and GXc = acat^T . v), and dbeta1 [2Cs+6Cv] = dbeta_perm in the reference's feature order.     */
-int svnet_edgeblock_bwd_mid_f32(const float* du_acc, const float* dvc, const float* dzp_acc, const float* dzc, int64_t P,
-                                int64_t Ov, float* acat, const float* dbeta_perm, int64_t Cs, int64_t Cv, float* dbeta1,
-                                void* stream);
+/* Reverse neighbour lists of a kNN graph (idx [B*N,k], cloud-local ids): the edges e = i*k + t that point at j are
+ * rev_edge[rev_range[2j] .. rev_range[2j+1]).  rev_range [2*B*N], rev_edge [B*N*k]; N <= 8192; ids outside [0,N) are skipped. */
+int svnet_knn_reverse_i32(const int64_t* idx, int64_t B, int64_t N, int64_t k, int32_t* rev_range, int32_t* rev_edge,
+                          void* stream);
+/* Row stride (floats) of the per-edge message rows msg[e] = [dL/dv' (3*Ov) | dL/ds_j (Cs) | dL/dv_j (3*Cv) | dL/dz (9) | pad]
+ * that svnet_edgeblock_bwd_f32 writes instead of scattering with float atomics.                                       */
+int64_t svnet_edgeblock_msg_stride(int64_t Cs, int64_t Cv, int64_t Ov);
+/* Sums the message rows over the reverse lists (one wave per destination point, no atomics) and finishes the point-level
+ * gradients: acat [3P, 2Ov+6] = [dU | dT | dZp | dZq] (dU = sum - dvc, dT = dvc, ...), ds_acc [P,Cs] += , dv_acc [P,3,Cv] +=,
+ * dbeta1 [2Cs+6Cv] = dbeta_perm in the reference's feature order.                                                     */
+int svnet_edgeblock_bwd_gather_f32(const float* msg, const int32_t* rev_range, const int32_t* rev_edge, const float* dvc,
+                                   const float* dzc, int64_t P, int64_t Cs, int64_t Cv, int64_t Ov, float* acat,
+                                   float* ds_acc, float* dv_acc, const float* dbeta_perm, float* dbeta1, void* stream);
 /* STE chain rule (svnet_binweight_grad_f32's formula, ASSIGNED) for linear1 from GXp [Os,320] (fused column order), for
  * linear2 from GXc[0:2Ov] and for the v2s frame from GXc[2Ov:2Ov+6]  (GXc [2Ov+6, Cv]).                              */
 int svnet_edgeblock_bwd_params_f32(const float* GXp, const float* GXc, const float* W1, const float* scale1, const float* W2,

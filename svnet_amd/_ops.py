@@ -633,9 +633,9 @@ class EdgeBlock(torch.autograd.Function):
         K1, R = 2 * Cs + 6 * Cv, 2 * Ov + 6
 
         # every accumulator of this backward from ONE zero fill
-        (red, redv, dgate, dWg0, dWg2, ds_acc, dv_acc, du_acc, dvc, dzp_acc, dzc, dbeta_perm, GXp, GXc) = _zeros_pool(
+        (red, redv, dgate, dWg0, dWg2, ds_acc, dv_acc, dzc, dbeta_perm, GXp, GXc) = _zeros_pool(
             dev, ((2 * Os,), F), ((2 * Ov,), F), ((B, Ov), F), ((H, 2 * Cs), F), ((Ov, H), F), ((P, Cs), F), ((P, 3, Cv), F),
-            ((P, 3, Ov), F), ((P, 3, Ov), F), ((P, 3, 3), F), ((P, 3, 3), F), ((320,), F), ((Os, 320), F), ((R, Cv), F))
+            ((P, 3, 3), F), ((320,), F), ((Os, 320), F), ((R, Cv), F))
 
         # ---- point-level prelude: BatchNorm reductions, gate gradient
         gy = torch.empty((P, Os), **f32)
@@ -667,16 +667,23 @@ class EdgeBlock(torch.autograd.Function):
         d.slot_max, d.slot_min, d.coef, d.gate = _p(slot_max), _p(slot_min), _p(coef), _p(gate)
         d.gy, d.bcoef, d.gv, d.gconst = _p(gy), _p(bcoef), _p(gv), _p(gconst)
         d.dn_out, d.x_sign32, d.x_nz32 = _p(dn_out), _p(x_sign), _p(x_nz)
-        d.ds_acc, d.dv_acc, d.du_acc, d.dvc = _p(ds_acc), _p(dv_acc), _p(du_acc), _p(dvc)
-        d.dzp_acc, d.dzc, d.dbeta_perm = _p(dzp_acc), _p(dzc), _p(dbeta_perm)
+        # the neighbour's share of every edge goes to a message row and is summed over the reverse neighbour lists (gather):
+        # float atomics are executed at the memory side on this part and were the bottleneck of the scatter formulation
+        rev_range = torch.empty((2 * P,), dtype=torch.int32, device=dev)
+        rev_edge = torch.empty((E,), dtype=torch.int32, device=dev)
+        call("svnet_knn_reverse_i32", _p(idx), B, N, k, _p(rev_range), _p(rev_edge), _stream())
+        msg = torch.empty((E, _lib.lib().svnet_edgeblock_msg_stride(Cs, Cv, Ov)), **f32)
+        dvc = torch.empty((P, 3, Ov), **f32)
+        d.msg, d.ds_acc, d.dv_acc, d.dvc, d.dzc, d.dbeta_perm = _p(msg), _p(ds_acc), _p(dv_acc), _p(dvc), _p(dzc), _p(dbeta_perm)
         d.debug = _p(DEBUG_BUFFER)
         call("svnet_edgeblock_bwd_f32", ctypes.byref(d), _stream())
 
-        # ---- gradient rows of the collapsed per-point products [U | T | Zp | Zq]; dbeta in the reference's feature order
+        # ---- neighbour sums -> gradient rows of the collapsed per-point products [U | T | Zp | Zq], ds, dv; dbeta in the
+        # reference's feature order
         acat = torch.empty((3 * P, R), **f32)
         dbeta1 = torch.empty((1, K1), **f32)
-        call("svnet_edgeblock_bwd_mid_f32", _p(du_acc), _p(dvc), _p(dzp_acc), _p(dzc), P, Ov, _p(acat), _p(dbeta_perm), Cs, Cv,
-             _p(dbeta1), _stream())
+        call("svnet_edgeblock_bwd_gather_f32", _p(msg), _p(rev_range), _p(rev_edge), _p(dvc), _p(dzc), P, Cs, Cv, Ov, _p(acat),
+             _p(ds_acc), _p(dv_acc), _p(dbeta_perm), _p(dbeta1), _stream())
         # linear1: GXp = dy^T . x_b (MFMA, ternary planes, fused column order)
         gemm(320, Os, E, a_planes=(x_sign, x_nz), B=dn_out, b_rs=Os, b_cs=1, C=GXp, ldc=1, c_cs=320, accumulate=True)
         # linear2 and the v2s frame: dv += (acat * scv) . wv ;  GXc = acat^T . v

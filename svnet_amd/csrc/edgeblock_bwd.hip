@@ -191,9 +191,12 @@ __global__ void edgeblock_bwd_coeffs_kernel(const float* __restrict__ red, const
     }
 }
 
+__device__ __forceinline__ int msg_stride(int Cs, int Cv, int Ov) { return ((3 * Ov + Cs + 3 * Cv + 9) + 3) / 4 * 4; }   // = svnet_edgeblock_msg_stride
+
 // ---------------------------------------------------------------------------------------------- vector path
 // dL/dv' of every edge (v' = U_j - U_i + T_i, out = gate * mean_k v'*(Av + Bv/n'), n' = |v'| + eps):
-//   du_acc[j] += dv' (float atomics, contiguous Ov-float segments),  dvc[i] = sum_k dv' (plain store: one wave owns a point).
+//   msg[e][0:3Ov] = dv' (the neighbour's share, summed over the reverse lists by the gather kernel),
+//   dvc[i] = sum_k dv' (plain store: one wave owns a point).
 // Wave per point like the forward; lanes = (edge slot g, channel c) with G = 64/Ov edges per wave-instruction.
 struct VecArgs {
     svnet_edgeblock_bwd_desc d;
@@ -217,6 +220,7 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_vec_kernel(VecArgs va) {
     const int Os = d.Os, Ov = d.Ov, k = (int)d.k;
     const int G = 64 / Ov, g = lane / Ov, c = lane - g * Ov;
     const bool act = g < G;
+    const int64_t R = msg_stride(d.Cs, d.Cv, Ov);
     const float* Av = d.coef + 4 * Os; const float* Bv = Av + Ov;
     const float* C0 = d.bcoef + 3 * Os; const float* C1 = C0 + Ov;
     const float avc = Av[c], bvc = Bv[c], c0 = C0[c], c1 = C1[c];
@@ -251,7 +255,6 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_vec_kernel(VecArgs va) {
     } while (0)
         SVNET_LOAD_U(0);
         for (int t0 = 0; t0 < k; t0 += G) {
-            const int64_t gj = n_gj;
             const bool ok = n_ok;
             const float u0 = n_u0, u1 = n_u1, u2 = n_u2;
             if (t0 + G < k) SVNET_LOAD_U(t0 + G);
@@ -263,10 +266,9 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_vec_kernel(VecArgs va) {
             const float dnn = -gdot * bvc / (nn * nn) + c0 + c1 * nn;
             const float kk = nv > 0.f ? dnn / nv : 0.f;
             const float d0 = ge0 * q + kk * vp0, d1 = ge1 * q + kk * vp1, d2 = ge2 * q + kk * vp2;
-            if (ok) {
-                ATOMIC_ADD(&d.du_acc[(gj * 3 + 0) * Ov + c], d0);
-                ATOMIC_ADD(&d.du_acc[(gj * 3 + 1) * Ov + c], d1);
-                ATOMIC_ADD(&d.du_acc[(gj * 3 + 2) * Ov + c], d2);
+            if (ok) {   // the neighbour's share goes into the edge's message row (summed over the reverse lists later)
+                float* m = d.msg + (gp * k + t0 + g) * R;
+                m[c] = d0; m[Ov + c] = d1; m[2 * Ov + c] = d2;
                 cv0 += d0; cv1 += d1; cv2 += d2;
             }
         }
@@ -502,6 +504,7 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
         float csum = 0.f;                           // centre part of ds for the current point (lane c < Cs)
         float cvd0 = 0.f, cvd1 = 0.f, cvd2 = 0.f;   // centre part of dv (diff lanes carry -sum, centre lanes +sum)
         float czq = 0.f, czq8 = 0.f;                // centre sums of dL/dz: packed (group g of 8 lanes: entry bitreverse3(g)), entry 8
+        const int64_t R = msg_stride(Cs, Cv, d.Ov);
         const int zq_idx = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2);   // bitreverse3(lane >> 3)
         const bool zq_writer = (lane & 7) == 0;
 
@@ -526,7 +529,7 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
             nx.valid = false;
             if (rr + 1 < TE / 4) load_edge(d, ew + rr + 1, E, lane, v2_lane, cm, nx);
             if (!in.valid) { in = nx; continue; }
-            const int64_t gp = in.gp, gj = in.gj;
+            const int64_t gp = in.gp;
             if (gp != cur_p) {
                 if (cur_p >= 0) SVNET_FLUSH_POINT(cur_p);
                 cur_p = gp;
@@ -557,15 +560,14 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
             czq8 += dz8;
             if (diff_lane) { cvd0 -= dve0; cvd1 -= dve1; cvd2 -= dve2; }
             else if (v2_lane) { cvd0 += dve0; cvd1 += dve1; cvd2 += dve2; }
-            // ---- scatter to the neighbour's rows (one contiguous segment per wave-instruction)
-            if (s_lane) ATOMIC_ADD(&d.ds_acc[gj * Cs + lane], d0);
-            if (diff_lane) {
-                ATOMIC_ADD(&d.dv_acc[(gj * 3 + 0) * Cv + lane], dve0);
-                ATOMIC_ADD(&d.dv_acc[(gj * 3 + 1) * Cv + lane], dve1);
-                ATOMIC_ADD(&d.dv_acc[(gj * 3 + 2) * Cv + lane], dve2);
+            // ---- the neighbour's share: plain stores into the edge's message row
+            {
+                float* m = d.msg + (ew + rr) * R + 3 * d.Ov;
+                if (s_lane) m[lane] = d0;
+                if (diff_lane) { m[Cs + lane] = dve0; m[Cs + Cv + lane] = dve1; m[Cs + 2 * Cv + lane] = dve2; }
+                if (zq_writer) m[Cs + 3 * Cv + zq_idx] = dzp;
+                if (lane == 63) m[Cs + 3 * Cv + 8] = dz8;
             }
-            if (zq_writer) ATOMIC_ADD(&d.dzp_acc[gj * 9 + zq_idx], dzp);
-            if (lane == 63) ATOMIC_ADD(&d.dzp_acc[gj * 9 + 8], dz8);
             in = nx;
         }
         if (cur_p >= 0) SVNET_FLUSH_POINT(cur_p);
@@ -637,7 +639,7 @@ extern "C" int svnet_edgeblock_bwd_f32(const svnet_edgeblock_bwd_desc* desc, voi
     const svnet_edgeblock_bwd_desc& d = *desc;
     SVNET_REQUIRE(d.v && d.idx && d.zz && d.ut && d.n16 && d.planes && d.w1bt && d.scale1 && d.slot_max && d.slot_min && d.coef &&
                       d.gate && d.gy && d.bcoef && d.gv && d.gconst && d.dn_out && d.x_sign32 && d.x_nz32 && d.ds_acc && d.dv_acc &&
-                      d.du_acc && d.dvc && d.dzp_acc && d.dzc && d.dbeta_perm,
+                      d.msg && d.dvc && d.dzc && d.dbeta_perm,
                   SVNET_E_ARG, "svnet_edgeblock_bwd_f32: null pointer");
     SVNET_REQUIRE(d.B >= 0 && d.N > 0 && d.k > 0 && d.k <= 255, SVNET_E_ARG, "svnet_edgeblock_bwd_f32: bad sizes");
     SVNET_REQUIRE(d.Cs > 0 && d.Cs <= 64 && d.Cv > 0 && 2 * d.Cv <= 64 && d.Os > 0 && d.Os <= 128 && d.Os % 8 == 0 && d.Ov > 0 &&

@@ -1,7 +1,8 @@
 // Small point-level / parameter-level stages around the fused edge pass of a binarized edge layer (edgeblock.hip,
 // edgeblock_bwd.hip).  Each replaces a handful of launch-bound framework ops by ONE launch:
 //   svnet_edgeblock_prepare_vec_f32 : sign(W2), sign(Wz) rearranged for the per-point products U|T and Zp|Zq
-//   svnet_edgeblock_bwd_mid_f32     : accumulators of the edge pass -> A = [dU | dT | dZp | dZq] rows, dbeta in reference order
+//   svnet_knn_reverse_i32           : reverse neighbour lists of a kNN graph (scatter -> gather)
+//   svnet_edgeblock_bwd_gather_f32  : neighbour sums of the per-edge message rows -> A = [dU | dT | dZp | dZq] rows, ds, dv, dbeta
 //   svnet_edgeblock_bwd_params_f32  : STE chain rule to (W1, scale1), (W2, scale2), (Wz, scalez) from the three Gram products
 // Reference: models/sv_layers.py:35-51 (Linear bw/ba), :172-196 (SVBlock), models/utils/sv_util.py:90-116 (edge features).
 #include "common.h"
@@ -26,32 +27,6 @@ __global__ void prepare_vec_kernel(const float* __restrict__ W2, const float* __
             const int r = e - R * Cv;
             scv[r] = r < 2 * Ov ? sc2[r % Ov] : scz[(r - 2 * Ov) % 3];
         }
-    }
-}
-
-// acat[(p,a), :] = [du - dvc | dvc | dzp - dzc | dzc];  dbeta1[f] = dbeta_perm[fused column of f]
-__global__ __launch_bounds__(256) void bwd_mid_kernel(const float* __restrict__ du, const float* __restrict__ dvc,
-                                                      const float* __restrict__ dzp, const float* __restrict__ dzc, int64_t rows,
-                                                      int Ov, float* __restrict__ acat, const float* __restrict__ dbeta_perm, int Cs,
-                                                      int Cv, float* __restrict__ dbeta1) {
-    const int W = 2 * Ov + 6;
-    const int64_t total = rows * W;
-    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (int64_t e = t0; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = e / W;
-        const int c = (int)(e - r * W);
-        float val;
-        if (c < Ov) val = du[r * Ov + c] - dvc[r * Ov + c];
-        else if (c < 2 * Ov) val = dvc[r * Ov + c - Ov];
-        else if (c < 2 * Ov + 3) val = dzp[r * 3 + c - 2 * Ov] - dzc[r * 3 + c - 2 * Ov];
-        else val = dzc[r * 3 + c - 2 * Ov - 3];
-        acat[e] = val;
-    }
-    const int K1 = 2 * Cs + 6 * Cv;
-    if (t0 < K1) {
-        const int f = (int)t0, g = f - 2 * Cs;
-        const int col = f < Cs ? f : (f < 2 * Cs ? 64 + f - Cs : 128 + 64 * (g % 3) + g / 3);
-        dbeta1[f] = dbeta_perm[col];
     }
 }
 
@@ -99,6 +74,126 @@ __global__ __launch_bounds__(256) void bwd_params_kernel(const float* __restrict
     if (lane == 0) (is2 ? dsc2 : dscz)[o] = part;
 }
 
+// ---- reverse neighbour lists of one kNN graph: for every point j the edges e = i*k + t with idx[e] == j, grouped by j
+// (rev_range[2j], rev_range[2j+1]) = [begin, end) into rev_edge.  One workgroup per cloud; counters and the scan live in
+// LDS (N <= 8192).  The order inside a list follows the LDS atomics and is not fixed from run to run.
+constexpr int REV_MAX_N = 8192;
+__global__ __launch_bounds__(1024) void knn_reverse_kernel(const int64_t* __restrict__ idx, int N, int k, int32_t* __restrict__ rev_range,
+                                                          int32_t* __restrict__ rev_edge) {
+    extern __shared__ int cnt[];          // [N] counts -> cursors; [N .. N+1024) scan scratch
+    int* part = cnt + N;
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int64_t e0 = (int64_t)b * N * k;
+    const int EN = N * k;
+    for (int j = tid; j < N; j += nt) cnt[j] = 0;
+    __syncthreads();
+    for (int e = tid; e < EN; e += nt) {
+        const int64_t j = idx[e0 + e];
+        if ((uint64_t)j < (uint64_t)N) atomicAdd(&cnt[(int)j], 1);     // out-of-range ids are skipped everywhere
+    }
+    __syncthreads();
+    // exclusive scan of cnt[0..N): each thread owns a contiguous run
+    const int per = (N + nt - 1) / nt;
+    const int j0 = min(tid * per, N), j1 = min(j0 + per, N);
+    int run = 0;
+    for (int j = j0; j < j1; ++j) run += cnt[j];
+    part[tid] = run;
+    __syncthreads();
+    for (int off = 1; off < nt; off <<= 1) {
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int base = part[tid] - run;          // exclusive prefix of this thread's run
+    for (int j = j0; j < j1; ++j) {
+        const int c = cnt[j];
+        rev_range[2 * ((int64_t)b * N + j)] = (int32_t)(e0 + base);
+        rev_range[2 * ((int64_t)b * N + j) + 1] = (int32_t)(e0 + base + c);
+        cnt[j] = base;                   // becomes the fill cursor
+        base += c;
+    }
+    __syncthreads();
+    for (int e = tid; e < EN; e += nt) {
+        const int64_t j = idx[e0 + e];
+        if ((uint64_t)j < (uint64_t)N) {
+            const int pos = atomicAdd(&cnt[(int)j], 1);
+            rev_edge[e0 + pos] = (int32_t)(e0 + e);
+        }
+    }
+}
+
+// ---- neighbour sums of the per-edge message rows msg[e] = [dv' (3 Ov) | ds (Cs) | dve (3 Cv) | dz (9)] over the reverse
+// lists: one wave per destination point, lanes = columns (NCH chunks of 64), the next row is loaded before the current
+// one is added.  Writes the gradient rows of the collapsed products directly:
+//   acat[(j,a), :] = [U_a - dvc | dvc | Z_a - dzc | dzc],   ds_acc[j] += S,   dv_acc[j] += V.
+template <int NCH>
+__global__ __launch_bounds__(256) void edgeblock_bwd_gather_kernel(const float* __restrict__ msg, const int32_t* __restrict__ rev_range,
+                                                                   const int32_t* __restrict__ rev_edge, const float* __restrict__ dvc,
+                                                                   const float* __restrict__ dzc, int64_t P, int Cs, int Cv, int Ov, int R,
+                                                                   float* __restrict__ acat, float* __restrict__ ds_acc,
+                                                                   float* __restrict__ dv_acc, const float* __restrict__ dbeta_perm,
+                                                                   float* __restrict__ dbeta1) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (blockIdx.x == 0) {       // dL/dbeta from the fused column order back to the reference's feature order
+        const int K1 = 2 * Cs + 6 * Cv;
+        for (int f = threadIdx.x; f < K1; f += blockDim.x) {
+            const int g = f - 2 * Cs;
+            const int col = f < Cs ? f : (f < 2 * Cs ? 64 + f - Cs : 128 + 64 * (g % 3) + g / 3);
+            dbeta1[f] = dbeta_perm[col];
+        }
+    }
+    if (j >= P) return;
+    const int beg = rev_range[2 * j], end = rev_range[2 * j + 1];
+    float acc[NCH], nx[NCH];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) acc[q] = 0.f;
+    int col[NCH];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) col[q] = min(64 * q + lane, R - 1);     // clamped: lanes past the row re-read its last column
+    if (beg < end) {
+        const float* row = msg + (int64_t)rev_edge[beg] * R;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) nx[q] = row[col[q]];
+    }
+    for (int n = beg; n < end; ++n) {
+        float cur[NCH];
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) cur[q] = nx[q];
+        if (n + 1 < end) {
+            const float* row = msg + (int64_t)rev_edge[n + 1] * R;
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) nx[q] = row[col[q]];
+        }
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) acc[q] += cur[q];
+    }
+    const int RW = 2 * Ov + 6;
+    const int oS = 3 * Ov, oV = oS + Cs, oZ = oV + 3 * Cv;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        const int c = 64 * q + lane;
+        if (c >= R) continue;
+        const float v = acc[q];
+        if (c < oS) {
+            const int a = c / Ov, o = c - a * Ov;
+            const float cen = dvc[(j * 3 + a) * Ov + o];
+            acat[(j * 3 + a) * RW + o] = v - cen;
+            acat[(j * 3 + a) * RW + Ov + o] = cen;
+        } else if (c < oV) {
+            ds_acc[j * Cs + (c - oS)] += v;
+        } else if (c < oZ) {
+            dv_acc[j * 3 * Cv + (c - oV)] += v;
+        } else if (c < oZ + 9) {
+            const int z = c - oZ, a = z / 3, jz = z - a * 3;
+            const float cen = dzc[j * 9 + z];
+            acat[(j * 3 + a) * RW + 2 * Ov + jz] = v - cen;
+            acat[(j * 3 + a) * RW + 2 * Ov + 3 + jz] = cen;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int svnet_edgeblock_prepare_vec_f32(const float* W2, const float* scale2, const float* Wz, const float* scalez, int64_t Ov,
@@ -108,18 +203,6 @@ extern "C" int svnet_edgeblock_prepare_vec_f32(const float* W2, const float* sca
     hipLaunchKernelGGL(prepare_vec_kernel, dim3(svnet_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, W2, scale2, Wz, scalez, (int)Ov,
                        (int)Cv, wv, scv);
     SVNET_CHECK_LAUNCH("prepare_vec_kernel");
-    return SVNET_OK;
-}
-
-extern "C" int svnet_edgeblock_bwd_mid_f32(const float* du_acc, const float* dvc, const float* dzp_acc, const float* dzc, int64_t P,
-                                           int64_t Ov, float* acat, const float* dbeta_perm, int64_t Cs, int64_t Cv, float* dbeta1,
-                                           void* stream) {
-    SVNET_REQUIRE(du_acc && dvc && dzp_acc && dzc && acat && dbeta_perm && dbeta1 && P > 0 && Ov > 0, SVNET_E_ARG,
-                  "svnet_edgeblock_bwd_mid_f32: bad arguments");
-    SVNET_REQUIRE(Cs > 0 && Cs <= 64 && Cv > 0 && 2 * Cv <= 64, SVNET_E_UNSUPPORTED, "svnet_edgeblock_bwd_mid_f32: needs Cs <= 64, 2*Cv <= 64");
-    hipLaunchKernelGGL(bwd_mid_kernel, dim3(svnet_grid(3 * P * (2 * Ov + 6), 256)), dim3(256), 0, (hipStream_t)stream, du_acc, dvc,
-                       dzp_acc, dzc, 3 * P, (int)Ov, acat, dbeta_perm, (int)Cs, (int)Cv, dbeta1);
-    SVNET_CHECK_LAUNCH("bwd_mid_kernel");
     return SVNET_OK;
 }
 
@@ -136,3 +219,44 @@ extern "C" int svnet_edgeblock_bwd_params_f32(const float* GXp, const float* GXc
     SVNET_CHECK_LAUNCH("bwd_params_kernel");
     return SVNET_OK;
 }
+
+extern "C" int svnet_knn_reverse_i32(const int64_t* idx, int64_t B, int64_t N, int64_t k, int32_t* rev_range, int32_t* rev_edge,
+                                     void* stream) {
+    SVNET_REQUIRE(idx && rev_range && rev_edge && B >= 0 && N > 0 && k > 0, SVNET_E_ARG, "svnet_knn_reverse_i32: bad arguments");
+    SVNET_REQUIRE(N <= REV_MAX_N, SVNET_E_UNSUPPORTED, "svnet_knn_reverse_i32: N=%lld > %d", (long long)N, REV_MAX_N);
+    SVNET_REQUIRE(B * N * k < (int64_t)1 << 31, SVNET_E_UNSUPPORTED, "svnet_knn_reverse_i32: more than 2^31 edges");
+    if (B == 0) return SVNET_OK;
+    hipLaunchKernelGGL(knn_reverse_kernel, dim3((unsigned)B), dim3(1024), (size_t)(N + 1024) * sizeof(int), (hipStream_t)stream, idx, (int)N,
+                       (int)k, rev_range, rev_edge);
+    SVNET_CHECK_LAUNCH("knn_reverse_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_edgeblock_bwd_gather_f32(const float* msg, const int32_t* rev_range, const int32_t* rev_edge, const float* dvc,
+                                              const float* dzc, int64_t P, int64_t Cs, int64_t Cv, int64_t Ov, float* acat,
+                                              float* ds_acc, float* dv_acc, const float* dbeta_perm, float* dbeta1, void* stream) {
+    SVNET_REQUIRE(msg && rev_range && rev_edge && dvc && dzc && acat && ds_acc && dv_acc && dbeta_perm && dbeta1 && P > 0, SVNET_E_ARG,
+                  "svnet_edgeblock_bwd_gather_f32: bad arguments");
+    SVNET_REQUIRE(Cs > 0 && Cs <= 64 && Cv > 0 && 2 * Cv <= 64 && Ov > 0 && Ov <= 64, SVNET_E_UNSUPPORTED,
+                  "svnet_edgeblock_bwd_gather_f32: needs Cs <= 64, 2*Cv <= 64, Ov <= 64");
+    const int R = (int)svnet_edgeblock_msg_stride(Cs, Cv, Ov);
+    const int nch = (R + 63) / 64;
+    const unsigned grid = (unsigned)svnet_cdiv(P, 4);
+    hipStream_t st = (hipStream_t)stream;
+#define SVNET_GATHER(NCH)                                                                                                         \
+    hipLaunchKernelGGL((edgeblock_bwd_gather_kernel<NCH>), dim3(grid), dim3(256), 0, st, msg, rev_range, rev_edge, dvc, dzc, P, (int)Cs, \
+                       (int)Cv, (int)Ov, R, acat, ds_acc, dv_acc, dbeta_perm, dbeta1)
+    switch (nch) {
+        case 1: SVNET_GATHER(1); break;
+        case 2: SVNET_GATHER(2); break;
+        case 3: SVNET_GATHER(3); break;
+        case 4: SVNET_GATHER(4); break;
+        case 5: SVNET_GATHER(5); break;
+        default: SVNET_GATHER(6); break;
+    }
+#undef SVNET_GATHER
+    SVNET_CHECK_LAUNCH("edgeblock_bwd_gather_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int64_t svnet_edgeblock_msg_stride(int64_t Cs, int64_t Cv, int64_t Ov) { return ((3 * Ov + Cs + 3 * Cv + 9) + 3) / 4 * 4; }
