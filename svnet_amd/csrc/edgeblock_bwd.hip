@@ -332,7 +332,8 @@ __device__ __forceinline__ void load_edge(const svnet_edgeblock_bwd_desc& d, int
     in.gc1 = d.gconst[in.b * 2 * Cs + Cs + ls];
 }
 
-template <int MODE>  // MODE: 0 = product; 1..3 = timing-only ablations (SVNET_BWD_MODE), wrong results
+// MODE: 0 = product; 1..3 = timing-only ablations (SVNET_BWD_MODE), wrong results.  NKS = k-steps of phase B (Os <= 16*NKS)
+template <int MODE, int NKS>
 __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_desc d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Cs = d.Cs, Cv = d.Cv, Os = d.Os;
@@ -360,6 +361,28 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
     const bool s_lane = lane < Cs, v2_lane = lane < 2 * Cv, diff_lane = lane < Cv;
     const int cm = diff_lane ? lane : lane - Cv;
 
+    // sign(W1) fragments of this wave's column tiles for phase B (NKS k-steps x 3 tiles x 4 VGPRs).  Up to Os = 64 they are
+    // requested before anything else, so that their L2 latency is hidden behind phase A (at Os = 128 the 96 registers would
+    // spill across phase A: loaded at the start of phase B instead)
+    const int nks = (Os + 15) >> 4;
+    bf16x8 bfr[NKS][3];
+#define SVNET_LOAD_BFR()                                                                                       \
+    do {                                                                                                       \
+        const int r_ = lane & 31, h_ = lane >> 5;                                                              \
+        const bf16x8* wbt_ = reinterpret_cast<const bf16x8*>(d.w1bt); /* [(col*Os + k) / 8] */                 \
+        _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks)                                                     \
+            _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                                    \
+                const int ct = wave + 4 * q, kk = ks * 16 + 8 * h_;                                            \
+                if (ks < nks && ct < NCOL / 32 && kk + 8 <= Os) {                                              \
+                    bfr[ks][q] = wbt_[((int64_t)(ct * 32 + r_) * Os + kk) >> 3];                               \
+                } else {                                                                                       \
+                    _Pragma("unroll") for (int j = 0; j < 8; ++j) bfr[ks][q][j] = bf16_from_bits(0);           \
+                }                                                                                              \
+            }                                                                                                  \
+    } while (0)
+    constexpr bool HOIST_B = NKS <= 4;
+    if (HOIST_B) SVNET_LOAD_BFR();
+
     // ================= phase A: dL/dy_pre of the tile's 32 x Os edge-channels from the saved integer sums =========
     //   dy_pre = cs*(g - m1 - xhat*m2), xhat = (scale*n - mean)*invstd, g = gy[p,o] on the pooled edge, else 0
     //          = cs*g - (alpha + beta*n)
@@ -380,34 +403,50 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
             const int plane = q / NW, w = q - plane * NW;
             pl[(plane * TE + r) * NW + w] = (e0 + r < E) ? d.planes[(e0 + r) * (3 * NW) + q] : 0ull;
         }
-        __syncthreads();
+        // this thread's edge-channel quads (<= 4: Os <= 128): their loads go out before the barrier, with the constants'
         const int O4 = Os >> 2;
         const int k = (int)d.k;
-        for (int item = tid; item < TE * O4; item += 256) {
+        constexpr int NI = NKS / 2;       // TE * (Os / 4) / 256 quads per thread
+        short4 n4[NI]; float4 gy4[NI]; uchar4 smx[NI], smn[NI]; int tt[NI];
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int item = it * 256 + tid;
             const int r = item / O4, o4 = (item - r * O4) << 2;
             const int64_t e = e0 + r;
-            float4 dn = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < E) {
+            tt[it] = -1;
+            if (item < TE * O4 && e < E) {
                 const int64_t gp = e / k;
-                const int t = (int)(e - gp * k);
-                const short4 n4 = *reinterpret_cast<const short4*>(d.n16 + e * Os + o4);
-                const float4 gy4 = *reinterpret_cast<const float4*>(d.gy + gp * Os + o4);
-                const uchar4 smx = *reinterpret_cast<const uchar4*>(d.slot_max + gp * Os + o4);
-                const uchar4 smn = *reinterpret_cast<const uchar4*>(d.slot_min + gp * Os + o4);
+                tt[it] = (int)(e - gp * k);
+                n4[it] = *reinterpret_cast<const short4*>(d.n16 + e * Os + o4);
+                gy4[it] = *reinterpret_cast<const float4*>(d.gy + gp * Os + o4);
+                smx[it] = *reinterpret_cast<const uchar4*>(d.slot_max + gp * Os + o4);
+                smn[it] = *reinterpret_cast<const uchar4*>(d.slot_min + gp * Os + o4);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int item = it * 256 + tid;
+            if (item >= TE * O4) break;
+            const int r = item / O4, o4 = (item - r * O4) << 2;
+            const int64_t e = e0 + r;
+            const int t = tt[it];
+            float4 dn = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t >= 0) {
                 const float4 cs = *reinterpret_cast<const float4*>(chc + o4);
                 const float4 al = *reinterpret_cast<const float4*>(chc + Os + o4);
                 const float4 be = *reinterpret_cast<const float4*>(chc + 2 * Os + o4);
                 const float4 sc = *reinterpret_cast<const float4*>(chc + 3 * Os + o4);
                 const float4 ps = *reinterpret_cast<const float4*>(chc + 4 * Os + o4);
-                const float g0 = ((ps.x != 0.f ? smx.x : smn.x) == t) ? gy4.x : 0.f;
-                const float g1 = ((ps.y != 0.f ? smx.y : smn.y) == t) ? gy4.y : 0.f;
-                const float g2 = ((ps.z != 0.f ? smx.z : smn.z) == t) ? gy4.z : 0.f;
-                const float g3 = ((ps.w != 0.f ? smx.w : smn.w) == t) ? gy4.w : 0.f;
+                const float g0 = ((ps.x != 0.f ? smx[it].x : smn[it].x) == t) ? gy4[it].x : 0.f;
+                const float g1 = ((ps.y != 0.f ? smx[it].y : smn[it].y) == t) ? gy4[it].y : 0.f;
+                const float g2 = ((ps.z != 0.f ? smx[it].z : smn[it].z) == t) ? gy4[it].z : 0.f;
+                const float g3 = ((ps.w != 0.f ? smx[it].w : smn[it].w) == t) ? gy4[it].w : 0.f;
                 float4 dy;
-                dy.x = cs.x * g0 - (al.x + be.x * (float)n4.x);
-                dy.y = cs.y * g1 - (al.y + be.y * (float)n4.y);
-                dy.z = cs.z * g2 - (al.z + be.z * (float)n4.z);
-                dy.w = cs.w * g3 - (al.w + be.w * (float)n4.w);
+                dy.x = cs.x * g0 - (al.x + be.x * (float)n4[it].x);
+                dy.y = cs.y * g1 - (al.y + be.y * (float)n4[it].y);
+                dy.z = cs.z * g2 - (al.z + be.z * (float)n4[it].z);
+                dy.w = cs.w * g3 - (al.w + be.w * (float)n4[it].w);
                 *reinterpret_cast<float4*>(d.dn_out + e * Os + o4) = dy;
                 dn = make_float4(dy.x * sc.x, dy.y * sc.y, dy.z * sc.z, dy.w * sc.w);
             }
@@ -421,14 +460,16 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
     {
         const int64_t word_row = e0 >> 6;
         const int half = (int)((e0 >> 5) & 1);
+        // lanes 0..31 hold the low and lanes 32..63 the high 32 bits of row (lane & 31): one ballot yields two columns
         for (int item = wave; item < 2 * NW; item += 4) {
             const int plane = item / NW, w = item - plane * NW;
-            const uint64_t mine = (lane < TE) ? pl[(plane * TE + lane) * NW + w] : 0ull;
+            const uint64_t roww = pl[(plane * TE + (lane & 31)) * NW + w];
+            const uint32_t mine = lane < 32 ? (uint32_t)roww : (uint32_t)(roww >> 32);
             uint32_t colword = 0u;
 #pragma unroll 8
-            for (int bb = 0; bb < 64; ++bb) {
-                const uint64_t tb = __ballot((mine >> bb) & 1ull);
-                if (lane == bb) colword = (uint32_t)tb;
+            for (int bb = 0; bb < 32; ++bb) {
+                const uint64_t tb = __ballot((mine >> bb) & 1u);
+                if ((lane & 31) == bb) colword = lane < 32 ? (uint32_t)tb : (uint32_t)(tb >> 32);
             }
             uint32_t* dst = plane == 0 ? d.x_sign32 : d.x_nz32;
             dst[((word_row * NCOL) + w * 64 + lane) * 2 + half] = colword;
@@ -438,30 +479,14 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
     // ================= phase B: dx_b = dnl . sign(W1), masked by the STE plane =================
     {
         const int r = lane & 31, h = lane >> 5;
-        const int nks = (Os + 15) >> 4;
-        const bf16x8* wbt = reinterpret_cast<const bf16x8*>(d.w1bt);   // [(col*Os + k) / 8]
+        if (!HOIST_B) SVNET_LOAD_BFR();
         f32x16 acc[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
-        // all B fragments of this wave's column tiles up front (<= 8 k-steps x 3 tiles x 4 VGPRs): one exposed
-        // L2 latency instead of one per k-step
-        bf16x8 bfr[8][3];
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int ct = wave + 4 * q, kk = ks * 16 + 8 * h;
-                if (ks < nks && ct < NCOL / 32 && kk + 8 <= Os) {
-                    bfr[ks][q] = wbt[((int64_t)(ct * 32 + r) * Os + kk) >> 3];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) bfr[ks][q][j] = bf16_from_bits(0);
-                }
-            }
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
+        for (int ks = 0; ks < NKS; ++ks) {
             if (ks < nks) {
                 const int kk = ks * 16 + 8 * h;
                 const float4 x0 = *reinterpret_cast<const float4*>(&dnl[r * DNS + kk]);      // DNS % 4 == 0, kk % 8 == 0
@@ -521,14 +546,20 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
         if (lane == 63) ATOMIC_ADD(&d.dzc[(p) * 9 + 8], czq8);                                                     \
     } while (0)
 
-        EdgeIn in, nx;
-        load_edge(d, ew, E, lane, v2_lane, cm, in);
+        // edge rows are requested two iterations ahead (a ring of four with compile-time slots: no register copies)
+        EdgeIn q[4];
+        load_edge(d, ew, E, lane, v2_lane, cm, q[0]);
+        load_edge(d, ew + 1, E, lane, v2_lane, cm, q[1]);
 #pragma unroll 1
-        for (int rr = 0; rr < TE / 4; ++rr) {
+        for (int r4 = 0; r4 < TE / 4; r4 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r4 + u;
             const int r = wave * (TE / 4) + rr;
-            nx.valid = false;
-            if (rr + 1 < TE / 4) load_edge(d, ew + rr + 1, E, lane, v2_lane, cm, nx);
-            if (!in.valid) { in = nx; continue; }
+            q[(u + 2) & 3].valid = false;
+            if (rr + 2 < TE / 4) load_edge(d, ew + rr + 2, E, lane, v2_lane, cm, q[(u + 2) & 3]);
+            const EdgeIn& in = q[u];
+            if (!in.valid) continue;
             const int64_t gp = in.gp;
             if (gp != cur_p) {
                 if (cur_p >= 0) SVNET_FLUSH_POINT(cur_p);
@@ -568,10 +599,11 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
                 if (zq_writer) m[Cs + 3 * Cv + zq_idx] = dzp;
                 if (lane == 63) m[Cs + 3 * Cv + 8] = dz8;
             }
-            in = nx;
+        }
         }
         if (cur_p >= 0) SVNET_FLUSH_POINT(cur_p);
 #undef SVNET_FLUSH_POINT
+#undef SVNET_LOAD_BFR
         // dL/dbeta: 320 addresses shared by the whole grid -> combine the four waves in LDS, one atomic per column
         // per workgroup (same-address float atomics serialise at the memory side)
         __syncthreads();                                     // every wave is done with dxl
@@ -665,7 +697,12 @@ extern "C" int svnet_edgeblock_bwd_f32(const svnet_edgeblock_bwd_desc* desc, voi
     // scalar path: 32-edge tiles
     const size_t lds = (size_t)TE * DXS * 4 + (size_t)3 * TE * NW * 8 + (size_t)5 * d.Os * 4;   // dnl aliases dxl
     const unsigned grid = (unsigned)svnet_cdiv(E, TE);
-#define SVNET_LAUNCH_BWD(MODE) hipLaunchKernelGGL((edgeblock_bwd_kernel<MODE>), dim3(grid), dim3(256), lds, st, d)
+#define SVNET_LAUNCH_BWD(MODE)                                                                                              \
+    do {                                                                                                                    \
+        if (d.Os <= 32) hipLaunchKernelGGL((edgeblock_bwd_kernel<MODE, 2>), dim3(grid), dim3(256), lds, st, d);             \
+        else if (d.Os <= 64) hipLaunchKernelGGL((edgeblock_bwd_kernel<MODE, 4>), dim3(grid), dim3(256), lds, st, d);        \
+        else hipLaunchKernelGGL((edgeblock_bwd_kernel<MODE, 8>), dim3(grid), dim3(256), lds, st, d);                        \
+    } while (0)
     if (mode == 1) SVNET_LAUNCH_BWD(1); else if (mode == 2) SVNET_LAUNCH_BWD(2); else if (mode == 3) SVNET_LAUNCH_BWD(3); else SVNET_LAUNCH_BWD(0);
 #undef SVNET_LAUNCH_BWD
     SVNET_CHECK_LAUNCH("edgeblock_bwd_kernel");
