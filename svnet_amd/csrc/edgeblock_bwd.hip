@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "prelude.h"
 
 namespace {
 
@@ -106,55 +107,12 @@ __global__ void edgeblock_wbt_kernel(const uint64_t* __restrict__ w_sign, const 
 }
 
 // ---------------------------------------------------------------------------------------------- point-level prelude
-// gy[p,o] = Gs * lrelu'(y*) ; red[0:Os] += gy ; red[Os:2Os] += gy * xhat*      (y*, xhat* at the pooled edge)
-// dgate[b,c] += sum_d Gv*(Av*mv + Bv*mvn) ; redv[0:Ov] += Gv*gate*mv ; redv[Ov:2Ov] += Gv*gate*mvn
 __global__ __launch_bounds__(256) void edgeblock_bwd_prelude_kernel(
     const float* __restrict__ gs, const float* __restrict__ gv, const int32_t* __restrict__ n_max, const int32_t* __restrict__ n_min,
     const float* __restrict__ mv, const float* __restrict__ mvn, const float* __restrict__ coef, const float* __restrict__ scale1,
     const float* __restrict__ gate, int64_t P, int64_t N, int Os, int Ov, float slope, int64_t rows_per_block,
     float* __restrict__ gy, float* __restrict__ red, float* __restrict__ redv, float* __restrict__ dgate) {
-    const float* A1 = coef; const float* B1 = coef + Os; const float* MY = coef + 2 * Os; const float* IY = coef + 3 * Os;
-    const float* Av = coef + 4 * Os; const float* Bv = Av + Ov;
-    const int64_t p0 = (int64_t)blockIdx.x * rows_per_block, p1 = min(P, p0 + rows_per_block);
-    for (int o = threadIdx.x; o < Os; o += blockDim.x) {
-        const float a = A1[o], bb = B1[o], sc = scale1[o], my = MY[o], iy = IY[o];
-        float r1 = 0.f, r2 = 0.f;
-        for (int64_t p = p0; p < p1; ++p) {
-            const float sel = (float)(a >= 0.f ? n_max[p * Os + o] : n_min[p * Os + o]);
-            const float y = a * sel + bb;
-            const float g = gs[p * Os + o] * (y > 0.f ? 1.f : slope);
-            gy[p * Os + o] = g;
-            r1 += g;
-            r2 += g * (sc * sel - my) * iy;
-        }
-        atomicAdd(&red[o], r1);
-        atomicAdd(&red[Os + o], r2);
-    }
-    for (int c = threadIdx.x; c < Ov; c += blockDim.x) {
-        const float av = Av[c], bv = Bv[c];
-        float ra = 0.f, rb = 0.f, gsum = 0.f;
-        int64_t cur_b = -1;
-        for (int64_t p = p0; p < p1; ++p) {
-            const int64_t b = p / N;
-            if (b != cur_b) {
-                if (cur_b >= 0) atomicAdd(&dgate[cur_b * Ov + c], gsum);
-                cur_b = b;
-                gsum = 0.f;
-            }
-            const float gt = gate[b * Ov + c];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const int64_t q = (p * 3 + d) * Ov + c;
-                const float g = gv[q], a = mv[q], n = mvn[q];
-                gsum += g * (av * a + bv * n);
-                ra += g * gt * a;
-                rb += g * gt * n;
-            }
-        }
-        if (cur_b >= 0) atomicAdd(&dgate[cur_b * Ov + c], gsum);
-        atomicAdd(&redv[c], ra);
-        atomicAdd(&redv[Ov + c], rb);
-    }
+    svnet_prelude_body<int32_t>(gs, gv, n_max, n_min, mv, mvn, coef, scale1, gate, P, N, Os, Ov, slope, rows_per_block, gy, red, redv, dgate);
 }
 
 // bcoef = [m1 | m2 | cs (Os each) | c0 | c1 (Ov each)];  BN parameter gradients written (not accumulated).
@@ -644,12 +602,10 @@ extern "C" int svnet_edgeblock_bwd_prelude_f32(const float* gs, const float* gv,
     SVNET_REQUIRE(gs && gv && n_max && n_min && mv && mvn && coef && scale1 && gate && gy && red && redv && dgate, SVNET_E_ARG,
                   "svnet_edgeblock_bwd_prelude_f32: null pointer");
     SVNET_REQUIRE(P > 0 && N > 0 && Os > 0 && Ov > 0, SVNET_E_ARG, "svnet_edgeblock_bwd_prelude_f32: bad sizes");
-    int64_t blocks = svnet_cdiv(P, 16);
-    if (blocks > 2048) blocks = 2048;
-    const int64_t rpb = svnet_cdiv(P, blocks);
-    blocks = svnet_cdiv(P, rpb);
-    hipLaunchKernelGGL(edgeblock_bwd_prelude_kernel, dim3((unsigned)blocks), dim3(128), 0, (hipStream_t)stream, gs, gv, n_max, n_min, mv,
-                       mvn, coef, scale1, gate, P, N, (int)Os, (int)Ov, slope, rpb, gy, red, redv, dgate);
+    SVNET_REQUIRE(Os <= 128 && Ov <= 64, SVNET_E_UNSUPPORTED, "svnet_edgeblock_bwd_prelude_f32: Os <= 128, Ov <= 64");
+    const int64_t rpb = svnet_prelude_rows(N);
+    hipLaunchKernelGGL(edgeblock_bwd_prelude_kernel, dim3((unsigned)svnet_cdiv(P, rpb)), dim3(256), 0, (hipStream_t)stream, gs, gv, n_max,
+                       n_min, mv, mvn, coef, scale1, gate, P, N, (int)Os, (int)Ov, slope, rpb, gy, red, redv, dgate);
     SVNET_CHECK_LAUNCH("edgeblock_bwd_prelude_kernel");
     return SVNET_OK;
 }

@@ -267,7 +267,9 @@ inline void reduce_geometry(int64_t M, int64_t C, int& cw_shift, int64_t& rpb, u
     cw_shift = ColMap::make(C).cw_shift;
     const int RL = 256 >> cw_shift;
     int64_t blocks = svnet_cdiv(M, (int64_t)RL * 8);  // >= 8 rows per thread
-    if (blocks > 2048) blocks = 2048;
+    // every workgroup ends with one atomic per output column onto the SAME 2C addresses, and same-address atomics
+    // serialise at the memory side: 512 workgroups (2 per CU) keep the loads flowing with 4x fewer of them than 2048
+    if (blocks > 512) blocks = 512;
     if (blocks < 1) blocks = 1;
     rpb = svnet_cdiv(svnet_cdiv(M, blocks), RL) * RL;
     grid = (unsigned)svnet_cdiv(M, rpb);

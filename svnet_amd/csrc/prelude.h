@@ -1,0 +1,78 @@
+// Point-level prelude shared by the backward of both fused edge layers (edgeblock_bwd.hip, xyzblock.hip):
+//   gy[p,o] = Gs * lrelu'(y*) ; red[0:Os] += gy ; red[Os:2Os] += gy * xhat*      (y*, xhat* at the pooled edge)
+//   dgate[b,c] += sum_d Gv*(Av*mv + Bv*mvn) ; redv[0:Ov] += Gv*gate*mv ; redv[Ov:2Ov] += Gv*gate*mvn
+// A workgroup owns rows_per_block points of ONE cloud; its 256 threads are (row group, channel), partial sums meet in
+// LDS and leave as one atomic per output per workgroup (the outputs are shared by the whole grid, and same-address
+// float atomics serialise at the memory side).
+#pragma once
+#include "common.h"
+
+template <typename SelT>
+__device__ __forceinline__ void svnet_prelude_body(const float* __restrict__ gs, const float* __restrict__ gv,
+                                                   const SelT* __restrict__ sel_max, const SelT* __restrict__ sel_min,
+                                                   const float* __restrict__ mv, const float* __restrict__ mvn,
+                                                   const float* __restrict__ coef, const float* __restrict__ scale1 /* or null */,
+                                                   const float* __restrict__ gate, int64_t P, int64_t N, int Os, int Ov, float slope,
+                                                   int64_t rows_per_block, float* __restrict__ gy, float* __restrict__ red,
+                                                   float* __restrict__ redv, float* __restrict__ dgate) {
+    __shared__ float lred[2 * 128 + 3 * 64];
+    const float* A1 = coef; const float* B1 = coef + Os; const float* MY = coef + 2 * Os; const float* IY = coef + 3 * Os;
+    const float* Av = coef + 4 * Os; const float* Bv = Av + Ov;
+    const int tid = threadIdx.x;
+    const int64_t p0 = (int64_t)blockIdx.x * rows_per_block, p1 = min(P, p0 + rows_per_block);
+    const int64_t b = p0 / N;                                   // rows_per_block divides N: one cloud per workgroup
+    for (int i = tid; i < 2 * Os + 3 * Ov; i += blockDim.x) lred[i] = 0.f;
+    __syncthreads();
+    {
+        int cw = 32;
+        while (cw < Os) cw <<= 1;
+        const int o = tid & (cw - 1), rg = tid / cw, RG = blockDim.x / cw;
+        if (o < Os) {
+            const float a = A1[o], bb = B1[o], sc = scale1 ? scale1[o] : 1.f, my = MY[o], iy = IY[o];
+            float r1 = 0.f, r2 = 0.f;
+            for (int64_t p = p0 + rg; p < p1; p += RG) {
+                const float sel = (float)(a >= 0.f ? sel_max[p * Os + o] : sel_min[p * Os + o]);
+                const float y = a * sel + bb;
+                const float g = gs[p * Os + o] * (y > 0.f ? 1.f : slope);
+                gy[p * Os + o] = g;
+                r1 += g;
+                r2 += g * (sc * sel - my) * iy;
+            }
+            atomicAdd(&lred[o], r1);
+            atomicAdd(&lred[Os + o], r2);
+        }
+    }
+    {
+        int cw = 32;
+        while (cw < Ov) cw <<= 1;
+        const int c = tid & (cw - 1), rg = tid / cw, RG = blockDim.x / cw;
+        if (c < Ov) {
+            const float av = Av[c], bv = Bv[c], gt = gate[b * Ov + c];
+            float ra = 0.f, rb = 0.f, gsum = 0.f;
+            for (int64_t p = p0 + rg; p < p1; p += RG) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const int64_t q = (p * 3 + d) * Ov + c;
+                    const float g = gv[q], a = mv[q], n = mvn[q];
+                    gsum += g * (av * a + bv * n);
+                    ra += g * gt * a;
+                    rb += g * gt * n;
+                }
+            }
+            atomicAdd(&lred[2 * Os + c], ra);
+            atomicAdd(&lred[2 * Os + Ov + c], rb);
+            atomicAdd(&lred[2 * Os + 2 * Ov + c], gsum);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * Os; i += blockDim.x) atomicAdd(&red[i], lred[i]);
+    for (int i = tid; i < 2 * Ov; i += blockDim.x) atomicAdd(&redv[i], lred[2 * Os + i]);
+    for (int i = tid; i < Ov; i += blockDim.x) atomicAdd(&dgate[b * Ov + i], lred[2 * Os + 2 * Ov + i]);
+}
+
+// rows per workgroup: the largest power of two <= 64 that divides N (a workgroup never spans two clouds)
+static inline int64_t svnet_prelude_rows(int64_t N) {
+    int64_t r = 64;
+    while (r > 1 && N % r != 0) r >>= 1;
+    return r;
+}
