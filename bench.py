@@ -128,7 +128,10 @@ def main():
 
     # roofline leg: HIP events around one entry point (eager launches on the current stream, outside the timed region
     # when a graph is replayed, inside it otherwise)
-    timer = _lib.KernelTimer(args.roofline_kernel)
+    # (the fused backward issues two launches per layer: parts=1 vector path on a side stream, parts=2 the 32-edge tile kernel;
+    #  the dominant kernel of the step is the tile kernel of conv4, Os = 128)
+    sel = (lambda a: a[0]._obj.parts == 2 and a[0]._obj.Os == 128) if args.roofline_kernel == "svnet_edgeblock_bwd_f32" else None
+    timer = _lib.KernelTimer(args.roofline_kernel, sel)
 
     def barrier():
         torch.cuda.synchronize()
@@ -159,26 +162,25 @@ def main():
 
     if rank == 0:
         clouds = B_PER_GPU * world * args.steps
-        # Dominant kernel of the step: the fused edge-block backward of conv4 (edgeblock_bwd_kernel<2>, one launch per
-        # step; the entry point is called for conv4, conv3, conv2 in that order).  Algorithmic HBM bytes of that launch
-        # (DESIGN.md §4): point tables + neighbour ids + pooled-edge operands read once, dL/dy and the ternary planes
-        # written once for the weight-gradient GEMM, point-level gradients written once.
+        # Dominant kernel of the step: edgeblock_bwd_kernel<0,8>, the 32-edge tile kernel of conv4's fused backward (one launch
+        # per step).  Algorithmic HBM bytes of that launch: per edge the kept n (2 B x Os) and planes (120 B) and
+        # the neighbour id are read, dL/dy (4 B x Os), the row-sliced sign/non-zero planes (80 B) and the message row
+        # (Cs + 3 Cv + 9 floats) are written; per point the pooled-edge operands / v / zz are read and the centre sums written.
         ms = timer.elapsed_ms()
         per_launch = None
         if ms:
             E = B_PER_GPU * N_POINTS * K_NN
             P_ = B_PER_GPU * N_POINTS
             Cs, Cv, Os, Ov = 64, 21, 128, 42
-            conv4 = [ms[i] for i in range(0, len(ms), 3)]
-            dur = sum(conv4) / len(conv4) * 1e-3
-            reads = P_ * 4 * (Cs + 3 * Cv + 18 + 6 * Ov) + E * 8 + P_ * Os * (1 + 4) + P_ * 3 * Ov * 4
-            writes = E * Os * 4 + 2 * (E // 8) * 320 + P_ * 4 * (Cs + 3 * Cv + 2 * 3 * Ov + 18)
+            dur = sum(ms) / len(ms) * 1e-3
+            reads = E * (2 * Os + 120 + 8) + P_ * (Os * (4 + 2) + 4 * (3 * Cv + 18))
+            writes = E * (4 * Os + 80 + 4 * (Cs + 3 * Cv + 9)) + P_ * 4 * (Cs + 3 * Cv + 9)
             alg = reads + writes
             per_launch = {"bound": "hbm", "achieved": round(alg / dur / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(alg / dur / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                          "kernel": "edgeblock_bwd_kernel<2> (conv4: Cs=64 Cv=21 -> Os=128 Ov=42)", "avg_launch_us": round(dur * 1e6, 1),
-                          "algorithmic_bytes": alg,
-                          "note": "latency/atomic-bound, not bandwidth-bound: 8 float-atomic row segments per edge; see DESIGN.md"}
+                          "kernel": "edgeblock_bwd_kernel<0,8> (conv4 backward tile kernel: Cs=64 Cv=21 -> Os=128 Ov=42)",
+                          "avg_launch_us": round(dur * 1e6, 1), "algorithmic_bytes": alg,
+                          "note": "instruction/latency-bound (64-lane waves carry 21..64 channels), not bandwidth-bound; see DESIGN.md"}
         out = {
             "metric": "point-clouds/sec fwd+bwd, sv_dgcnn_cls B=32 N=1024 k=20",
             "value": round(clouds / elapsed, 2), "unit": "point-clouds/sec", "n_gpus": world, "steps": args.steps,

@@ -183,6 +183,8 @@ typedef struct svnet_edgeblock_bwd_desc {
     float* msg;                  /* [E, svnet_edgeblock_msg_stride]: per-edge neighbour contributions (written, not accumulated) */
     float* ds_acc; float* dv_acc; float* dvc; float* dzc; float* dbeta_perm;   /* centre sums (atomics) / dvc written */
     int64_t* debug;              /* optional [4]: {count, first bad edge, its idx value, N}; edges with idx outside [0,N) are skipped */
+    int parts;                   /* 0 or 3: both kernels; 1: vector path only (msg[:, :3Ov], dvc); 2: scalar/tile path only.  The two
+                                    are independent, so a caller may issue them on two streams                                   */
 } svnet_edgeblock_bwd_desc;
 int svnet_edgeblock_wbt_bf16(const uint64_t* w_sign, const uint64_t* w_nz, int64_t Os, uint16_t* wbt, void* stream);
 /* gy = Gs*lrelu'(y) at the pooled edge; red [2*Os], redv [2*Ov], dgate [B,Ov] accumulate (caller zero-fills).      */

@@ -68,6 +68,7 @@ class EdgeBlockBwdDesc(ctypes.Structure):
         ("msg", c_p),
         ("ds_acc", c_p), ("dv_acc", c_p), ("dvc", c_p), ("dzc", c_p), ("dbeta_perm", c_p),
         ("debug", c_p),
+        ("parts", c_int),
     ]
 
 

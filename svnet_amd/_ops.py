@@ -676,19 +676,31 @@ class EdgeBlock(torch.autograd.Function):
         dvc = torch.empty((P, 3, Ov), **f32)
         d.msg, d.ds_acc, d.dv_acc, d.dvc, d.dzc, d.dbeta_perm = _p(msg), _p(ds_acc), _p(dv_acc), _p(dvc), _p(dzc), _p(dbeta_perm)
         d.debug = _p(DEBUG_BUFFER)
+        # the vector path (wave per point) and the scalar path (32-edge tiles) are independent: two streams, so that the
+        # register/LDS-bound tile kernel and the light vector kernel share the CUs
+        main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            d.parts = 1
+            call("svnet_edgeblock_bwd_f32", ctypes.byref(d), _stream())
+        d.parts = 2
         call("svnet_edgeblock_bwd_f32", ctypes.byref(d), _stream())
 
         # ---- neighbour sums -> gradient rows of the collapsed per-point products [U | T | Zp | Zq], ds, dv; dbeta in the
         # reference's feature order
         acat = torch.empty((3 * P, R), **f32)
         dbeta1 = torch.empty((1, K1), **f32)
-        call("svnet_edgeblock_bwd_gather_f32", _p(msg), _p(rev_range), _p(rev_edge), _p(dvc), _p(dzc), P, Cs, Cv, Ov, _p(acat),
-             _p(ds_acc), _p(dv_acc), _p(dbeta_perm), _p(dbeta1), _stream())
-        # linear1: GXp = dy^T . x_b (MFMA, ternary planes, fused column order)
+        # linear1's weight-gradient product GXp = dy^T . x_b (MFMA, ternary planes, fused column order) only needs the tile
+        # kernel's outputs: it keeps the main stream while the side stream (joined with main first) sums the messages
+        side.wait_stream(main)
         gemm(320, Os, E, a_planes=(x_sign, x_nz), B=dn_out, b_rs=Os, b_cs=1, C=GXp, ldc=1, c_cs=320, accumulate=True)
-        # linear2 and the v2s frame: dv += (acat * scv) . wv ;  GXc = acat^T . v
-        gemm(3 * P, Cv, R, A=acat, a_rs=R, a_cs=1, a_scale=scv, B=wv, b_rs=Cv, b_cs=1, b_exact=True, C=dv_acc, ldc=Cv, accumulate=True)
-        gemm(R, Cv, 3 * P, A=acat, a_rs=1, a_cs=R, B=v, b_rs=Cv, b_cs=1, C=GXc, ldc=Cv, accumulate=True)
+        with torch.cuda.stream(side):
+            call("svnet_edgeblock_bwd_gather_f32", _p(msg), _p(rev_range), _p(rev_edge), _p(dvc), _p(dzc), P, Cs, Cv, Ov, _p(acat),
+                 _p(ds_acc), _p(dv_acc), _p(dbeta_perm), _p(dbeta1), _stream())
+            # linear2 and the v2s frame: dv += (acat * scv) . wv ;  GXc = acat^T . v
+            gemm(3 * P, Cv, R, A=acat, a_rs=R, a_cs=1, a_scale=scv, B=wv, b_rs=Cv, b_cs=1, b_exact=True, C=dv_acc, ldc=Cv, accumulate=True)
+            gemm(R, Cv, 3 * P, A=acat, a_rs=1, a_cs=R, B=v, b_rs=Cv, b_cs=1, C=GXc, ldc=Cv, accumulate=True)
+        main.wait_stream(side)
         dW1, dW2, dWz = torch.empty((Os, K1), **f32), torch.empty((Ov, 2 * Cv), **f32), torch.empty((3, 2 * Cv), **f32)
         dsc1, dsc2, dscz = torch.empty((Os,), **f32), torch.empty((Ov,), **f32), torch.empty((3,), **f32)
         call("svnet_edgeblock_bwd_params_f32", _p(GXp), _p(GXc), _p(W1), _p(sc1), _p(W2), _p(sc2), _p(Wz), _p(scz), Os, Ov, Cs, Cv,
@@ -789,6 +801,18 @@ class XyzBlock(torch.autograd.Function):
         dWz = gw[o + Ov * 2 + 6:].view(3, 2)
         # forward args: x, idx, k, training, W0, Wz, W1, g1, b1, rm1, rv1, W2, g2, b2, rm2, rv2, Wg0, Wg2
         return (None, None, None, None, dW0, dWz, dW1, dg1, db1, None, None, dW2, dg2, db2, None, None, dWg0, dWg2, None, None)
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    """One extra HIP stream per device for independent kernels of a fused backward (forked / joined with events, so the
+    pattern is also valid inside a hipGraph capture)."""
+    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return _SIDE_STREAMS[key]
 
 
 _PERM_CACHE = {}

@@ -646,9 +646,13 @@ extern "C" int svnet_edgeblock_bwd_f32(const svnet_edgeblock_bwd_desc* desc, voi
     va.points_per_wave = (int)svnet_cdiv(d.N, wpc);
     va.waves_per_cloud = (int)svnet_cdiv(d.N, va.points_per_wave);
     const unsigned vgrid = (unsigned)svnet_cdiv(d.B * va.waves_per_cloud, 4);
-    if (mode == 1) hipLaunchKernelGGL((edgeblock_bwd_vec_kernel<1>), dim3(vgrid), dim3(256), 0, st, va);
-    else hipLaunchKernelGGL((edgeblock_bwd_vec_kernel<0>), dim3(vgrid), dim3(256), 0, st, va);
-    SVNET_CHECK_LAUNCH("edgeblock_bwd_vec_kernel");
+    const bool do_vec = d.parts == 0 || (d.parts & 1), do_tile = d.parts == 0 || (d.parts & 2);
+    if (do_vec) {
+        if (mode == 1) hipLaunchKernelGGL((edgeblock_bwd_vec_kernel<1>), dim3(vgrid), dim3(256), 0, st, va);
+        else hipLaunchKernelGGL((edgeblock_bwd_vec_kernel<0>), dim3(vgrid), dim3(256), 0, st, va);
+        SVNET_CHECK_LAUNCH("edgeblock_bwd_vec_kernel");
+    }
+    if (!do_tile) return SVNET_OK;
 
     // scalar path: 32-edge tiles
     const size_t lds = (size_t)TE * DXS * 4 + (size_t)3 * TE * NW * 8 + (size_t)5 * d.Os * 4;   // dnl aliases dxl
