@@ -160,25 +160,52 @@ __device__ __forceinline__ void wave_argmax(float& v, int& j) {
 // "a ranks before b": larger value first, equal values -> smaller index first
 __device__ __forceinline__ bool ranks_before(float va, int ja, float vb, int jb) { return (va > vb) || (va == vb && ja < jb); }
 
-// Bitonic sort of one (value, index) pair per lane across the wave; afterwards lane 0 holds the best pair, lane 63 the worst.
-__device__ __forceinline__ void wave_sort_desc(float& v, int& j, int lane) {
-#pragma unroll
-    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
-#pragma unroll
-        for (int s2 = k2 >> 1; s2 > 0; s2 >>= 1) {
-            const float ov = __shfl_xor(v, s2, 64);
-            const int oj = __shfl_xor(j, s2, 64);
-            const bool desc = (lane & k2) == 0 || k2 == 64;   // final merge: whole wave descending
-            const bool lower = (lane & s2) == 0;
-            const bool other_first = ranks_before(ov, oj, v, j);
-            // in a descending block the lower lane keeps the pair that ranks first, the upper lane the other one
-            const bool take = (lower == desc) ? other_first : !other_first;
-            v = take ? ov : v;
-            j = take ? oj : j;
-        }
+// Value of lane (l ^ S) without the LDS crossbar: DPP modifiers inside a 16-lane row, the gfx950 row / half swaps across rows
+// (a bitonic sort is a chain of 21 dependent exchanges, so the ~100-cycle ds_bpermute round trip was its whole cost).
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, false);
+}
+template <int S>
+__device__ __forceinline__ uint32_t lane_xor_u32(uint32_t x, int lane) {
+    if (S == 1) return dpp_u32<0xB1>(x);                       // quad_perm [1,0,3,2]
+    if (S == 2) return dpp_u32<0x4E>(x);                       // quad_perm [2,3,0,1]
+    if (S == 4) {                                              // rotate the row by 4 either way, keep the one that is l ^ 4
+        const uint32_t a = dpp_u32<0x124>(x), b = dpp_u32<0x12C>(x);   // row_ror:4 reads lane l-4, row_ror:12 reads lane l+4 (mod 16)
+        return (lane & 4) ? a : b;
     }
+    if (S == 8) return dpp_u32<0x128>(x);                      // row_ror:8
+    if (S == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        return (lane & 16) ? r[0] : r[1];
+    }
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return (lane & 32) ? r[0] : r[1];
 }
 
+// Bitonic sort of one (value, index) pair per lane across the wave; afterwards lane 0 holds the best pair, lane 63 the worst.
+template <int K2, int S2>
+__device__ __forceinline__ void sort_step(float& v, int& j, int lane) {
+    const float ov = __uint_as_float(lane_xor_u32<S2>(__float_as_uint(v), lane));
+    const int oj = (int)lane_xor_u32<S2>((uint32_t)j, lane);
+    const bool desc = (lane & K2) == 0 || K2 == 64;   // final merge: whole wave descending
+    const bool lower = (lane & S2) == 0;
+    const bool other_first = (ov > v) || (ov == v && oj < j);
+    // in a descending block the lower lane keeps the pair that ranks first, the upper lane the other one
+    const bool take = (lower == desc) ? other_first : !other_first;
+    v = take ? ov : v;
+    j = take ? oj : j;
+}
+__device__ __forceinline__ void wave_sort_desc(float& v, int& j, int lane) {
+    sort_step<2, 1>(v, j, lane);
+    sort_step<4, 2>(v, j, lane); sort_step<4, 1>(v, j, lane);
+    sort_step<8, 4>(v, j, lane); sort_step<8, 2>(v, j, lane); sort_step<8, 1>(v, j, lane);
+    sort_step<16, 8>(v, j, lane); sort_step<16, 4>(v, j, lane); sort_step<16, 2>(v, j, lane); sort_step<16, 1>(v, j, lane);
+    sort_step<32, 16>(v, j, lane); sort_step<32, 8>(v, j, lane); sort_step<32, 4>(v, j, lane); sort_step<32, 2>(v, j, lane);
+    sort_step<32, 1>(v, j, lane);
+    sort_step<64, 32>(v, j, lane); sort_step<64, 16>(v, j, lane); sort_step<64, 8>(v, j, lane); sort_step<64, 4>(v, j, lane);
+    sort_step<64, 2>(v, j, lane); sort_step<64, 1>(v, j, lane);
+}
 // T candidates per lane (64*T >= N), Q query rows per wave, 4 waves per workgroup.
 template <int T, int Q>
 __global__ __launch_bounds__(256) void knn_main_kernel(const float* __restrict__ xT, const float* __restrict__ xx,
@@ -204,20 +231,33 @@ __global__ __launch_bounds__(256) void knn_main_kernel(const float* __restrict__
 #pragma unroll
     for (int q = 0; q < Q; ++q) qi[q] = min(q0 + q, N - 1);
 
+    // channel c+1's candidate row and query values are requested before channel c's FMAs (the chain over c is what fixes
+    // the rounding, so the loop cannot be reordered, only overlapped)
+    int jc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) jc[t] = min(lane + 64 * t, N - 1);    // clamped: lanes past N are overwritten with -inf below
+    float cn[T], qn[Q];
+#pragma unroll
+    for (int t = 0; t < T; ++t) cn[t] = xb[jc[t]];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) qn[q] = xb[qi[q]];                     // wave-uniform address -> scalar load
     for (int c = 0; c < C; ++c) {
-        const float* __restrict__ row = xb + (size_t)c * N;
-        float cand[T];
+        float cand[T], qv[Q];
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int j = lane + 64 * t;
-            cand[t] = (j < N) ? row[j] : 0.f;
+        for (int t = 0; t < T; ++t) cand[t] = cn[t];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) qv[q] = qn[q];
+        if (c + 1 < C) {
+            const float* __restrict__ row = xb + (size_t)(c + 1) * N;
+#pragma unroll
+            for (int t = 0; t < T; ++t) cn[t] = row[jc[t]];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) qn[q] = row[qi[q]];
         }
 #pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const float qv = row[qi[q]];  // wave-uniform address -> scalar load
+        for (int q = 0; q < Q; ++q)
 #pragma unroll
-            for (int t = 0; t < T; ++t) acc[q][t] = __builtin_fmaf(qv, cand[t], acc[q][t]);
-        }
+            for (int t = 0; t < T; ++t) acc[q][t] = __builtin_fmaf(qv[q], cand[t], acc[q][t]);
     }
 
     float xxj[T];
