@@ -154,7 +154,7 @@ extern "C" int svnet_gemm_f32(const svnet_gemm_desc* desc, void* stream) {
                              d.accumulate, st);
     }
     // ---- rows x exact-bf16 weights
-    if (d.b_exact && d.a_cs == 1 && d.c_cs == 1 && d.M >= 256 && d.K >= 8) return svnet_mfma_rows(d, st);
+    if (d.b_exact && d.a_cs == 1 && d.c_cs == 1 && d.M >= 16 && d.K >= 8) return svnet_mfma_rows(d, st);
 
     GemmArgs ga;
     ga.d = d;

@@ -507,7 +507,8 @@ int svnet_mfma_rows(const svnet_gemm_desc& d, hipStream_t st) {
     a.alpha = d.alpha; a.col_scale = d.col_scale; a.bias = d.bias;
     a.mask = d.mask; a.col_sum = d.col_sum; a.accumulate = d.accumulate;
     a.a_vec = (d.a_rs % 4 == 0) && (reinterpret_cast<uintptr_t>(d.A) % 16 == 0);
-    if (d.N <= 32) launch_rows<1>(a, st);
+    // few row blocks (the classifier head: M = batch): narrow column tiles so that the grid still has tens of workgroups
+    if (d.N <= 32 || d.M <= 512) launch_rows<1>(a, st);
     else if (d.N <= 64) launch_rows<2>(a, st);
     else if (d.N <= 128) launch_rows<4>(a, st);
     else launch_rows<8>(a, st);
