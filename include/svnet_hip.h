@@ -183,7 +183,7 @@ typedef struct svnet_edgeblock_bwd_desc {
     float* msg;                  /* [E, svnet_edgeblock_msg_stride]: per-edge neighbour contributions (written, not accumulated) */
     float* ds_acc; float* dv_acc; float* dvc; float* dzc; float* dbeta_perm;   /* centre sums (atomics) / dvc written */
     int64_t* debug;              /* optional [4]: {count, first bad edge, its idx value, N}; edges with idx outside [0,N) are skipped */
-    int parts;                   /* 0 or 3: both kernels; 1: vector path only (msg[:, :3Ov], dvc); 2: scalar/tile path only.  The two
+    int parts;                   /* 0 or 3: both kernels; 1: vector path only (the dL/dv' columns of msg, dvc); 2: scalar/tile path only.  The two
                                     are independent, so a caller may issue them on two streams                                   */
 } svnet_edgeblock_bwd_desc;
 int svnet_edgeblock_wbt_bf16(const uint64_t* w_sign, const uint64_t* w_nz, int64_t Os, uint16_t* wbt, void* stream);
@@ -201,7 +201,7 @@ int svnet_edgeblock_bwd_f32(const svnet_edgeblock_bwd_desc* desc, void* stream);
  * rev_edge[rev_range[2j] .. rev_range[2j+1]).  rev_range [2*B*N], rev_edge [B*N*k]; N <= 8192; ids outside [0,N) are skipped. */
 int svnet_knn_reverse_i32(const int64_t* idx, int64_t B, int64_t N, int64_t k, int32_t* rev_range, int32_t* rev_edge,
                           void* stream);
-/* Row stride (floats) of the per-edge message rows msg[e] = [dL/dv' (3*Ov) | dL/ds_j (Cs) | dL/dv_j (3*Cv) | dL/dz (9) | pad]
+/* Row stride (floats) of the per-edge message rows msg[e] = [dL/ds_j (Cs) | dL/dv_j (3*Cv) | dL/dz (9) | dL/dv' (3*Ov) | pad]
  * that svnet_edgeblock_bwd_f32 writes instead of scattering with float atomics.                                       */
 int64_t svnet_edgeblock_msg_stride(int64_t Cs, int64_t Cv, int64_t Ov);
 /* Sums the message rows over the reverse lists (one wave per destination point, no atomics) and finishes the point-level

@@ -26,6 +26,17 @@ namespace {
 
 #define ATOMIC_ADD(p, v) do { if (MODE != 1) atomicAdd((p), (v)); else asm volatile("" :: "v"(v)); } while (0)
 
+// Optional phase stopwatch (-DSVNET_PHASE_CLOCK, diagnostic builds only): thread 0 of every workgroup adds the cycles between
+// phase boundaries to debug[8 + phase]; debug must then hold >= 16 entries.
+#ifdef SVNET_PHASE_CLOCK
+#define PHASE_MARK(i) do { if (threadIdx.x == 0 && d.debug) { const long long t_ = clock64(); \
+        atomicAdd(reinterpret_cast<unsigned long long*>(d.debug) + 8 + (i), (unsigned long long)(t_ - ph_t)); ph_t = t_; } } while (0)
+#define PHASE_INIT() long long ph_t = clock64()
+#else
+#define PHASE_MARK(i) do { } while (0)
+#define PHASE_INIT() do { } while (0)
+#endif
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -153,7 +164,7 @@ __device__ __forceinline__ int msg_stride(int Cs, int Cv, int Ov) { return ((3 *
 
 // ---------------------------------------------------------------------------------------------- vector path
 // dL/dv' of every edge (v' = U_j - U_i + T_i, out = gate * mean_k v'*(Av + Bv/n'), n' = |v'| + eps):
-//   msg[e][0:3Ov] = dv' (the neighbour's share, summed over the reverse lists by the gather kernel),
+//   msg[e][Cs+3Cv+9 : +3Ov] = dv' (the neighbour's share, summed over the reverse lists by the gather kernel),
 //   dvc[i] = sum_k dv' (plain store: one wave owns a point).
 // Wave per point like the forward; lanes = (edge slot g, channel c) with G = 64/Ov edges per wave-instruction.
 struct VecArgs {
@@ -225,7 +236,7 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_vec_kernel(VecArgs va) {
             const float kk = nv > 0.f ? dnn / nv : 0.f;
             const float d0 = ge0 * q + kk * vp0, d1 = ge1 * q + kk * vp1, d2 = ge2 * q + kk * vp2;
             if (ok) {   // the neighbour's share goes into the edge's message row (summed over the reverse lists later)
-                float* m = d.msg + (gp * k + t0 + g) * R;
+                float* m = d.msg + (gp * k + t0 + g) * R + (d.Cs + 3 * d.Cv + 9);
                 m[c] = d0; m[Ov + c] = d1; m[2 * Ov + c] = d2;
                 cv0 += d0; cv1 += d1; cv2 += d2;
             }
@@ -252,12 +263,11 @@ struct EdgeIn {
     bool valid;
     float vi0, vi1, vi2, vj0, vj1, vj2;           // lane c2 < 2Cv (vj: diff lanes only)
     float z0, z1, z2, z3, z4, z5, z6, z7, z8;     // z[d*3+jz] = Zp_j - Zp_i + Zq_i
-    float gc0, gc1;                               // lane c < Cs: gate-path constants
 };
 
 __device__ __forceinline__ void load_edge(const svnet_edgeblock_bwd_desc& d, int64_t e, int64_t E, int lane, bool v2_lane, int cm,
                                           EdgeIn& in) {
-    const int Cs = d.Cs, Cv = d.Cv, k = (int)d.k;
+    const int Cv = d.Cv, k = (int)d.k;
     in.valid = e < E;
     if (!in.valid) return;
     in.gp = e / k;
@@ -274,7 +284,7 @@ __device__ __forceinline__ void load_edge(const svnet_edgeblock_bwd_desc& d, int
     const int64_t gp = in.gp, gj = in.gj;
     // clamped lane indices: every lane issues every load (no exec-masked branches, loads go out back to back);
     // lanes outside a channel range read a valid neighbour element that is masked where it is consumed
-    const int ls = min(lane, Cs - 1), ld = min(lane, Cv - 1), lc = v2_lane ? cm : 0;
+    const int ld = min(lane, Cv - 1), lc = v2_lane ? cm : 0;
     in.vi0 = d.v[(gp * 3 + 0) * Cv + lc];
     in.vi1 = d.v[(gp * 3 + 1) * Cv + lc];
     in.vi2 = d.v[(gp * 3 + 2) * Cv + lc];
@@ -286,8 +296,6 @@ __device__ __forceinline__ void load_edge(const svnet_edgeblock_bwd_desc& d, int
     in.z0 = zj[0] + (zi[3] - zi[0]);    in.z1 = zj[1] + (zi[4] - zi[1]);    in.z2 = zj[2] + (zi[5] - zi[2]);
     in.z3 = zj[6] + (zi[9] - zi[6]);    in.z4 = zj[7] + (zi[10] - zi[7]);   in.z5 = zj[8] + (zi[11] - zi[8]);
     in.z6 = zj[12] + (zi[15] - zi[12]); in.z7 = zj[13] + (zi[16] - zi[13]); in.z8 = zj[14] + (zi[17] - zi[14]);
-    in.gc0 = d.gconst[in.b * 2 * Cs + ls];
-    in.gc1 = d.gconst[in.b * 2 * Cs + Cs + ls];
 }
 
 // MODE: 0 = product; 1..3 = timing-only ablations (SVNET_BWD_MODE), wrong results.  NKS = k-steps of phase B (Os <= 16*NKS)
@@ -302,6 +310,7 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
     uint64_t* pl = reinterpret_cast<uint64_t*>(dxl + TE * DXS);      // [3][TE][NW] sign | nz | ste (row-major words)
     float* chc = reinterpret_cast<float*>(pl + 3 * TE * NW);         // [5][Os]     per-channel constants of phase A
 
+    PHASE_INIT();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // uniform: scalar loads / SGPR addressing
     const int64_t E = d.B * d.N * d.k;
@@ -316,7 +325,7 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
     const int64_t e0 = tile * TE;
     const int64_t ew = e0 + wave * (TE / 4);                          // first edge row of this wave
 
-    const bool s_lane = lane < Cs, v2_lane = lane < 2 * Cv, diff_lane = lane < Cv;
+    const bool v2_lane = lane < 2 * Cv, diff_lane = lane < Cv;
     const int cm = diff_lane ? lane : lane - Cv;
 
     // sign(W1) fragments of this wave's column tiles for phase B (NKS k-steps x 3 tiles x 4 VGPRs).  Up to Os = 64 they are
@@ -412,6 +421,7 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
         }
     }
     __syncthreads();
+    PHASE_MARK(0);   // phase A
     if (MODE == 2) return;
 
     // ---- ternary planes of this tile -> row-sliced 32-bit halves (rows = the tile's 32 edges)
@@ -434,6 +444,7 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
         }
     }
 
+    PHASE_MARK(1);   // plane transposition
     // ================= phase B: dx_b = dnl . sign(W1), masked by the STE plane =================
     {
         const int r = lane & 31, h = lane >> 5;
@@ -478,23 +489,72 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
         }
     }
     __syncthreads();
+    PHASE_MARK(2);   // phase B
     if (MODE == 3) return;
 
-    // ================= phase C: scatter the input gradients =================
+    // ================= phase C1 (all 256 threads over the tile): s part and dL/dbeta =================
+    //   msg[e][c]   = dx[e][c] + gconst0[c]                                  (the neighbour's share of ds)
+    //   ds_acc[i,c] += sum over the point's edges of dx[e][64+c] + gconst1[c] - msg[e][c]
+    //   dbeta_perm  += column sums of dx
+    const int64_t R = msg_stride(Cs, Cv, d.Ov);
     {
-        float dbd = 0.f, dbc = 0.f, dbv0 = 0.f, dbv1 = 0.f, dbv2 = 0.f;
+        const int k = (int)d.k;
+        const int64_t e_end = min(E, e0 + TE);
+        const int64_t gp_first = e0 / k;
+        const int npt = (int)((e_end - 1) / k - gp_first) + 1;          // points touched by this tile
+        float* csl = reinterpret_cast<float*>(pl);                        // the planes are dead after phase B: [npt][Cs] centre sums
+        const bool use_lds = npt * Cs <= 3 * TE * NW * 2;                 // floats in the planes region (k >= 3 at Cs = 64)
+        __shared__ int row_slot[TE], row_gc[TE];                          // per row: point slot inside the tile (-1 past E), gconst row offset
+        if (tid < TE) {
+            const int64_t e = e0 + tid;
+            const int64_t gp = e / k;
+            row_slot[tid] = e < E ? (int)(gp - gp_first) : -1;
+            row_gc[tid] = (int)(gp / d.N) * 2 * Cs;
+        }
+        if (use_lds) for (int i = tid; i < npt * Cs; i += 256) csl[i] = 0.f;
+        __syncthreads();
+        {
+            const int cw_shift = Cs <= 32 ? 5 : 6;                        // threads = (row group, channel): shifts, no divisions
+            const int c = tid & ((1 << cw_shift) - 1), rg = tid >> cw_shift, RG = 256 >> cw_shift;
+            if (c < Cs) {
+                for (int r = rg; r < TE; r += RG) {
+                    const int slot = row_slot[r];
+                    if (slot < 0) continue;
+                    const float* gcb = d.gconst + row_gc[r];
+                    const float d0 = dxl[r * DXS + c] + gcb[c];
+                    d.msg[(e0 + r) * R + c] = d0;
+                    const float cen = (dxl[r * DXS + 64 + c] + gcb[Cs + c]) - d0;
+                    if (use_lds) atomicAdd(&csl[slot * Cs + c], cen);
+                    else ATOMIC_ADD(&d.ds_acc[(gp_first + slot) * Cs + c], cen);
+                }
+            }
+        }
+        for (int col = tid; col < NCOL; col += 256) {                     // rows past E hold zeros
+            float sum = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < TE; ++r) sum += dxl[r * DXS + col];
+            if (sum != 0.f) ATOMIC_ADD(&d.dbeta_perm[col], sum);
+        }
+        __syncthreads();
+        if (use_lds)
+            for (int i = tid; i < npt * Cs; i += 256) {
+                const float v = csl[i];
+                if (v != 0.f) ATOMIC_ADD(&d.ds_acc[gp_first * Cs + i], v);
+            }
+    }
+
+    PHASE_MARK(3);   // phase C1
+    // ================= phase C2 (lanes = vector channels, one edge per wave iteration): v2s backward =================
+    {
         int64_t cur_p = -1;
-        float csum = 0.f;                           // centre part of ds for the current point (lane c < Cs)
         float cvd0 = 0.f, cvd1 = 0.f, cvd2 = 0.f;   // centre part of dv (diff lanes carry -sum, centre lanes +sum)
         float czq = 0.f, czq8 = 0.f;                // centre sums of dL/dz: packed (group g of 8 lanes: entry bitreverse3(g)), entry 8
-        const int64_t R = msg_stride(Cs, Cv, d.Ov);
         const int zq_idx = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2);   // bitreverse3(lane >> 3)
         const bool zq_writer = (lane & 7) == 0;
 
 // (a macro: a by-reference lambda forces the per-point accumulators into scratch memory)
 #define SVNET_FLUSH_POINT(p)                                                                                      \
     do {                                                                                                          \
-        if (s_lane) ATOMIC_ADD(&d.ds_acc[(p) * Cs + lane], csum);                                                  \
         if (v2_lane) {                                                                                            \
             ATOMIC_ADD(&d.dv_acc[((p) * 3 + 0) * Cv + cm], cvd0);                                                  \
             ATOMIC_ADD(&d.dv_acc[((p) * 3 + 1) * Cv + cm], cvd1);                                                  \
@@ -522,18 +582,11 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
             if (gp != cur_p) {
                 if (cur_p >= 0) SVNET_FLUSH_POINT(cur_p);
                 cur_p = gp;
-                csum = 0.f;
                 cvd0 = cvd1 = cvd2 = 0.f;
                 czq = czq8 = 0.f;
             }
             const float* row = dxl + r * DXS;
-            const float gx0 = s_lane ? row[lane] : 0.f;            // d/d(s_j - s_i) through the binarization
-            const float gx1 = s_lane ? row[64 + lane] : 0.f;       // d/d(s_i)
             const float g0 = v2_lane ? row[128 + lane] : 0.f, g1 = v2_lane ? row[192 + lane] : 0.f, g2 = v2_lane ? row[256 + lane] : 0.f;
-            dbd += gx0; dbc += gx1; dbv0 += g0; dbv1 += g1; dbv2 += g2;
-            const float gc0 = s_lane ? in.gc0 : 0.f, gc1 = s_lane ? in.gc1 : 0.f;   // gate path (not binarized)
-            const float d0 = gx0 + gc0;
-            csum += (gx1 + gc1) - d0;
             // v2s backward: s_v[c2][jz] = sum_d ve[d][c2] * z[d][jz]
             const float ve0 = diff_lane ? (in.vj0 - in.vi0) : (v2_lane ? in.vi0 : 0.f);
             const float ve1 = diff_lane ? (in.vj1 - in.vi1) : (v2_lane ? in.vi1 : 0.f);
@@ -551,38 +604,18 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
             else if (v2_lane) { cvd0 += dve0; cvd1 += dve1; cvd2 += dve2; }
             // ---- the neighbour's share: plain stores into the edge's message row
             {
-                float* m = d.msg + (ew + rr) * R + 3 * d.Ov;
-                if (s_lane) m[lane] = d0;
-                if (diff_lane) { m[Cs + lane] = dve0; m[Cs + Cv + lane] = dve1; m[Cs + 2 * Cv + lane] = dve2; }
-                if (zq_writer) m[Cs + 3 * Cv + zq_idx] = dzp;
-                if (lane == 63) m[Cs + 3 * Cv + 8] = dz8;
+                float* m = d.msg + (ew + rr) * R + Cs;
+                if (diff_lane) { m[lane] = dve0; m[Cv + lane] = dve1; m[2 * Cv + lane] = dve2; }
+                if (zq_writer) m[3 * Cv + zq_idx] = dzp;
+                if (lane == 63) m[3 * Cv + 8] = dz8;
             }
         }
         }
         if (cur_p >= 0) SVNET_FLUSH_POINT(cur_p);
 #undef SVNET_FLUSH_POINT
 #undef SVNET_LOAD_BFR
-        // dL/dbeta: 320 addresses shared by the whole grid -> combine the four waves in LDS, one atomic per column
-        // per workgroup (same-address float atomics serialise at the memory side)
-        __syncthreads();                                     // every wave is done with dxl
-        float* red = dxl;
-        for (int i = tid; i < NCOL; i += 256) red[i] = 0.f;
-        __syncthreads();
-        if (s_lane) {
-            ATOMIC_ADD(&red[lane], dbd);
-            ATOMIC_ADD(&red[64 + lane], dbc);
-        }
-        if (v2_lane) {
-            ATOMIC_ADD(&red[128 + lane], dbv0);
-            ATOMIC_ADD(&red[192 + lane], dbv1);
-            ATOMIC_ADD(&red[256 + lane], dbv2);
-        }
-        __syncthreads();
-        for (int i = tid; i < NCOL; i += 256) {
-            const float v = red[i];
-            if (v != 0.f) ATOMIC_ADD(&d.dbeta_perm[i], v);
-        }
     }
+    PHASE_MARK(4);   // phase C2 (wave 0 of the workgroup)
 }
 
 }  // namespace

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int64_t* __rest
     }
 }
 
-// ---- neighbour sums of the per-edge message rows msg[e] = [dv' (3 Ov) | ds (Cs) | dve (3 Cv) | dz (9)] over the reverse
+// ---- neighbour sums of the per-edge message rows msg[e] = [ds (Cs) | dve (3 Cv) | dz (9) | dv' (3 Ov)] over the reverse
 // lists: one wave per destination point, lanes = columns (NCH chunks of 64), the next row is loaded before the current
 // one is added.  Writes the gradient rows of the collapsed products directly:
 //   acat[(j,a), :] = [U_a - dvc | dvc | Z_a - dzc | dzc],   ds_acc[j] += S,   dv_acc[j] += V.
@@ -170,26 +170,26 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_gather_kernel(const float* 
         for (int q = 0; q < NCH; ++q) acc[q] += cur[q];
     }
     const int RW = 2 * Ov + 6;
-    const int oS = 3 * Ov, oV = oS + Cs, oZ = oV + 3 * Cv;
+    const int oV = Cs, oZ = oV + 3 * Cv, oU = oZ + 9;                 // msg row = [ds (Cs) | dve (3 Cv) | dz (9) | dv' (3 Ov) | pad]
 #pragma unroll
     for (int q = 0; q < NCH; ++q) {
         const int c = 64 * q + lane;
-        if (c >= R) continue;
+        if (c >= oU + 3 * Ov) continue;
         const float v = acc[q];
-        if (c < oS) {
-            const int a = c / Ov, o = c - a * Ov;
-            const float cen = dvc[(j * 3 + a) * Ov + o];
-            acat[(j * 3 + a) * RW + o] = v - cen;
-            acat[(j * 3 + a) * RW + Ov + o] = cen;
-        } else if (c < oV) {
-            ds_acc[j * Cs + (c - oS)] += v;
+        if (c < oV) {
+            ds_acc[j * Cs + c] += v;
         } else if (c < oZ) {
             dv_acc[j * 3 * Cv + (c - oV)] += v;
-        } else if (c < oZ + 9) {
+        } else if (c < oU) {
             const int z = c - oZ, a = z / 3, jz = z - a * 3;
             const float cen = dzc[j * 9 + z];
             acat[(j * 3 + a) * RW + 2 * Ov + jz] = v - cen;
             acat[(j * 3 + a) * RW + 2 * Ov + 3 + jz] = cen;
+        } else {
+            const int u = c - oU, a = u / Ov, o = u - a * Ov;
+            const float cen = dvc[(j * 3 + a) * Ov + o];
+            acat[(j * 3 + a) * RW + o] = v - cen;
+            acat[(j * 3 + a) * RW + Ov + o] = cen;
         }
     }
 }

@@ -1,0 +1,41 @@
+"""Per-phase cycle counts of edgeblock_bwd_kernel (diagnostic): builds a -DSVNET_PHASE_CLOCK copy of the library into
+gpurun_out/, runs one fused backward per layer shape and prints the mean cycles each workgroup spent per phase."""
+import os, subprocess, sys, shutil
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) == 1:
+    out = os.path.join(root, "gpurun_out", "phase_lib")
+    os.makedirs(out, exist_ok=True)
+    src = os.path.join(root, "svnet_amd", "csrc")
+    objs = []
+    for f in sorted(os.listdir(src)):
+        if f.endswith(".hip") or f == "error.cpp":
+            o = os.path.join(out, f + ".o")
+            flags = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-DSVNET_PHASE_CLOCK"]
+            if f == "knn.hip":
+                flags.append("-ffp-contract=off")
+            subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-c", os.path.join(src, f), "-o", o])
+            objs.append(o)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(out, "libsvnet_hip.so")] + objs)
+    env = dict(os.environ, SVNET_HIP_LIB=os.path.join(out, "libsvnet_hip.so"))
+    sys.exit(subprocess.call([sys.executable, __file__, "run"], env=env))
+import torch, contextlib, io
+sys.path.insert(0, root)
+from svnet_amd import _lib, _ops, config
+_lib.LIB_PATH = os.environ["SVNET_HIP_LIB"]
+from svnet_amd.models.sv_layers import SVBlock
+from svnet_amd.models.utils.sv_util import get_graph_feature_sv, svpool
+config.FUSE_EDGE_BLOCKS = True
+names = ["A", "transpose", "B", "C1", "C2"]
+for (Cs, Cv, Os, Ov) in [(32, 10, 32, 10), (32, 10, 64, 21), (64, 21, 128, 42)]:
+    with contextlib.redirect_stdout(io.StringIO()):
+        blk = SVBlock((2 * Cs, 2 * Cv), (Os, Ov), binary=True).cuda().train()
+    s = torch.randn(32, 1024, Cs, device="cuda", requires_grad=True)
+    v = torch.randn(32, 1024, 3, Cv, device="cuda", requires_grad=True)
+    for it in range(3):
+        _ops.DEBUG_BUFFER = torch.zeros(16, dtype=torch.int64, device="cuda")
+        so, vo = svpool(blk(get_graph_feature_sv((s, v), k=20)))
+        (so.sum() + vo.sum()).backward()
+        torch.cuda.synchronize()
+    cyc = _ops.DEBUG_BUFFER.cpu().tolist()[8:13]
+    tiles = 32 * 1024 * 20 // 32
+    print("Os=%d" % Os, " ".join("%s=%d" % (n, c // tiles) for n, c in zip(names, cyc)), "cycles per workgroup (clock64 ticks)", flush=True)

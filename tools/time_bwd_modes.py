@@ -14,7 +14,8 @@ if len(sys.argv) > 1:
         s = torch.randn(32, 1024, Cs, device="cuda", requires_grad=True)
         v = torch.randn(32, 1024, 3, Cv, device="cuda", requires_grad=True)
         for name in ("svnet_edgeblock_bwd_f32", "svnet_edgeblock_fwd_f32"):
-            t = _lib.KernelTimer(name)
+            sel = (lambda a: a[0]._obj.parts == 2) if name == "svnet_edgeblock_bwd_f32" else None   # the tile kernel
+            t = _lib.KernelTimer(name, sel)
             _lib.TIMER = t
             for _ in range(4):
                 so, vo = svpool(blk(get_graph_feature_sv((s, v), k=20)))
