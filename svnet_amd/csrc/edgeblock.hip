@@ -116,8 +116,14 @@ __global__ __launch_bounds__(256) void edgeblock_fwd_kernel(FwdArgs fa) {
     double sv1 = 0.0, sv2 = 0.0;
     float gs_diff = 0.f, gs_cen = 0.f;
 
+    // Neighbour ids: lane t of one coalesced load holds idx[p][t] (k <= 64) and v_readlane hands it to the scalar unit, so the
+    // gathers of an edge never wait on a load of their own index; the next point's ids are requested a whole point ahead.
+    const int lk = min(lane, k - 1);
+    int jv_next = (p_begin < p_end) ? (int)d.idx[(b * d.N + p_begin) * k + lk] : 0;
     for (int p = p_begin; p < p_end; ++p) {
         const int64_t gp = b * d.N + p;
+        const int jv = jv_next;
+        if (p + 1 < p_end) jv_next = (int)d.idx[(gp + 1) * k + lk];
         const float s_i = s_lane ? d.s[gp * Cs + min(lane, Cs - 1)] : 0.f;
         gs_cen += s_i;
         const float tc = s_i + bc;
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(256) void edgeblock_fwd_kernel(FwdArgs fa) {
         float n_sj, n_vj0, n_vj1, n_vj2, n_u0, n_u1, n_u2, n_z[9];
 #define SVNET_LOAD_NBR(T)                                                                   \
     do {                                                                                    \
-        const int64_t gj_ = b * d.N + d.idx[gp * k + (T)];                                  \
+        const int64_t gj_ = b * d.N + __builtin_amdgcn_readlane(jv, (T));                   \
         n_sj = d.s[gj_ * Cs + ls];                                                          \
         n_vj0 = d.v[(gj_ * 3 + 0) * Cv + ld]; n_vj1 = d.v[(gj_ * 3 + 1) * Cv + ld]; n_vj2 = d.v[(gj_ * 3 + 2) * Cv + ld]; \
         n_u0 = d.ut[(gj_ * 3 + 0) * 2 * Ov + lo]; n_u1 = d.ut[(gj_ * 3 + 1) * 2 * Ov + lo]; n_u2 = d.ut[(gj_ * 3 + 2) * 2 * Ov + lo]; \
@@ -368,7 +374,8 @@ extern "C" int svnet_edgeblock_fwd_f32(const svnet_edgeblock_desc* desc, void* s
                       d.slot_min && d.mv && d.mvn && d.gate_sum, SVNET_E_ARG, "svnet_edgeblock_fwd_f32: null pointer");
     SVNET_REQUIRE((d.stat_n == nullptr) == (d.stat_v == nullptr), SVNET_E_ARG, "svnet_edgeblock_fwd_f32: pass both stat buffers or none");
     SVNET_REQUIRE((d.n16 == nullptr) == (d.planes == nullptr), SVNET_E_ARG, "svnet_edgeblock_fwd_f32: pass both n16 and planes or none");
-    SVNET_REQUIRE(d.B >= 0 && d.N > 0 && d.k > 0 && d.k <= 255, SVNET_E_ARG, "svnet_edgeblock_fwd_f32: bad sizes");
+    SVNET_REQUIRE(d.B >= 0 && d.N > 0 && d.k > 0, SVNET_E_ARG, "svnet_edgeblock_fwd_f32: bad sizes");
+    SVNET_REQUIRE(d.k <= 64, SVNET_E_UNSUPPORTED, "svnet_edgeblock_fwd_f32: k=%lld > 64", (long long)d.k);
     SVNET_REQUIRE(d.Cs > 0 && d.Cs <= 64 && d.Cv > 0 && 2 * d.Cv <= 64 && d.Os > 0 && d.Os <= 128 && d.Ov > 0 && d.Ov <= 64,
                   SVNET_E_UNSUPPORTED, "svnet_edgeblock_fwd_f32: channel counts outside Cs<=64, 2Cv<=64, Os<=128, Ov<=64");
     if (d.B == 0) return SVNET_OK;

@@ -195,8 +195,14 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_vec_kernel(VecArgs va) {
     const float avc = Av[c], bvc = Bv[c], c0 = C0[c], c1 = C1[c];
     const float gtk = d.gate[b * Ov + c] / (float)k;
 
+    // neighbour ids of a point: one coalesced load (lane t holds idx[p][t], k <= 64), requested a point ahead; each lane picks
+    // its edge slot's id with a cross-lane read, so the row gathers never wait on a load of their own index
+    const int lk = min(lane, k - 1);
+    int jv_next = (p_begin < p_end) ? (int)d.idx[(b * d.N + p_begin) * k + lk] : 0;
     for (int p = p_begin; p < p_end; ++p) {
         const int64_t gp = b * d.N + p;
+        const int jv = jv_next;
+        if (p + 1 < p_end) jv_next = (int)d.idx[(gp + 1) * k + lk];
         const float* ui = d.ut + gp * 6 * Ov;
         const float ub0 = ui[0 * 2 * Ov + Ov + c] - ui[0 * 2 * Ov + c];   // T_i - U_i
         const float ub1 = ui[1 * 2 * Ov + Ov + c] - ui[1 * 2 * Ov + c];
@@ -209,7 +215,8 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_vec_kernel(VecArgs va) {
     do {                                                                                            \
         const int t_ = (T0) + g;                                                                    \
         n_ok = act && t_ < k;                                                                       \
-        int64_t jl_ = n_ok ? d.idx[gp * k + t_] : 0;                                                \
+        int64_t jl_ = __shfl(jv, min(t_, k - 1));                                                   \
+        if (!n_ok) jl_ = 0;                                                                         \
         if ((uint64_t)jl_ >= (uint64_t)d.N) { /* corrupted neighbour id: never dereference it */   \
             if (d.debug && c == 0) {                                                                \
                 if (atomicAdd(reinterpret_cast<unsigned long long*>(d.debug), 1ull) == 0ull) {      \
@@ -265,17 +272,39 @@ struct EdgeIn {
     float z0, z1, z2, z3, z4, z5, z6, z7, z8;     // z[d*3+jz] = Zp_j - Zp_i + Zq_i
 };
 
-__device__ __forceinline__ void load_edge(const svnet_edgeblock_bwd_desc& d, int64_t e, int64_t E, int lane, bool v2_lane, int cm,
-                                          EdgeIn& in) {
-    const int Cv = d.Cv, k = (int)d.k;
-    in.valid = e < E;
+// Row cursor of a wave: edge id, its point / cloud / slot, advanced one edge at a time (no 64-bit divisions in the loop).
+struct EdgeCursor {
+    int64_t e, gp, b;
+    int t, pin;
+};
+__device__ __forceinline__ void cursor_init(const svnet_edgeblock_bwd_desc& d, int64_t e, EdgeCursor& c) {
+    const int k = (int)d.k;
+    c.e = e;
+    c.gp = e / k;
+    c.t = (int)(e - c.gp * k);
+    c.b = c.gp / d.N;
+    c.pin = (int)(c.gp - c.b * d.N);
+}
+__device__ __forceinline__ void cursor_next(const svnet_edgeblock_bwd_desc& d, EdgeCursor& c) {
+    ++c.e;
+    if (++c.t == (int)d.k) {
+        c.t = 0;
+        ++c.gp;
+        if (++c.pin == (int)d.N) { c.pin = 0; ++c.b; }
+    }
+}
+
+// jloc: the edge's neighbour id (wave-uniform, from the wave's pre-loaded id vector)
+__device__ __forceinline__ void load_edge(const svnet_edgeblock_bwd_desc& d, const EdgeCursor& c, int64_t jloc, int64_t E, int lane,
+                                          bool v2_lane, int cm, EdgeIn& in) {
+    const int Cv = d.Cv;
+    in.valid = c.e < E;
     if (!in.valid) return;
-    in.gp = e / k;
-    in.b = in.gp / d.N;
-    const int64_t jloc = d.idx[e];
+    in.gp = c.gp;
+    in.b = c.b;
     if ((uint64_t)jloc >= (uint64_t)d.N) {  // corrupted neighbour id: never dereference it
         if (d.debug && lane == 0) {
-            if (atomicAdd(reinterpret_cast<unsigned long long*>(d.debug), 1ull) == 0ull) { d.debug[1] = e; d.debug[2] = jloc; d.debug[3] = d.N; }
+            if (atomicAdd(reinterpret_cast<unsigned long long*>(d.debug), 1ull) == 0ull) { d.debug[1] = c.e; d.debug[2] = jloc; d.debug[3] = d.N; }
         }
         in.valid = false;
         return;
@@ -327,6 +356,9 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
 
     const bool v2_lane = lane < 2 * Cv, diff_lane = lane < Cv;
     const int cm = diff_lane ? lane : lane - Cv;
+    // neighbour ids of this wave's 8 edge rows for phase C2 (lane rr holds idx[ew + rr]): requested now, consumed through
+    // v_readlane, so the row gathers of phase C2 never wait on a load of their own index
+    const int jv8 = (int)d.idx[min(ew + (lane & 7), E - 1)];
 
     // sign(W1) fragments of this wave's column tiles for phase B (NKS k-steps x 3 tiles x 4 VGPRs).  Up to Os = 64 they are
     // requested before anything else, so that their L2 latency is hidden behind phase A (at Os = 128 the 96 registers would
@@ -566,8 +598,11 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
 
         // edge rows are requested two iterations ahead (a ring of four with compile-time slots: no register copies)
         EdgeIn q[4];
-        load_edge(d, ew, E, lane, v2_lane, cm, q[0]);
-        load_edge(d, ew + 1, E, lane, v2_lane, cm, q[1]);
+        EdgeCursor cur;
+        cursor_init(d, ew, cur);
+        load_edge(d, cur, __builtin_amdgcn_readlane(jv8, 0), E, lane, v2_lane, cm, q[0]);
+        cursor_next(d, cur);
+        load_edge(d, cur, __builtin_amdgcn_readlane(jv8, 1), E, lane, v2_lane, cm, q[1]);
 #pragma unroll 1
         for (int r4 = 0; r4 < TE / 4; r4 += 4) {
 #pragma unroll
@@ -575,7 +610,10 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
             const int rr = r4 + u;
             const int r = wave * (TE / 4) + rr;
             q[(u + 2) & 3].valid = false;
-            if (rr + 2 < TE / 4) load_edge(d, ew + rr + 2, E, lane, v2_lane, cm, q[(u + 2) & 3]);
+            if (rr + 2 < TE / 4) {
+                cursor_next(d, cur);
+                load_edge(d, cur, __builtin_amdgcn_readlane(jv8, rr + 2), E, lane, v2_lane, cm, q[(u + 2) & 3]);
+            }
             const EdgeIn& in = q[u];
             if (!in.valid) continue;
             const int64_t gp = in.gp;
@@ -662,7 +700,7 @@ extern "C" int svnet_edgeblock_bwd_f32(const svnet_edgeblock_bwd_desc* desc, voi
                       d.gate && d.gy && d.bcoef && d.gv && d.gconst && d.dn_out && d.x_sign32 && d.x_nz32 && d.ds_acc && d.dv_acc &&
                       d.msg && d.dvc && d.dzc && d.dbeta_perm,
                   SVNET_E_ARG, "svnet_edgeblock_bwd_f32: null pointer");
-    SVNET_REQUIRE(d.B >= 0 && d.N > 0 && d.k > 0 && d.k <= 255, SVNET_E_ARG, "svnet_edgeblock_bwd_f32: bad sizes");
+    SVNET_REQUIRE(d.B >= 0 && d.N > 0 && d.k > 0 && d.k <= 64, SVNET_E_ARG, "svnet_edgeblock_bwd_f32: bad sizes (k <= 64)");
     SVNET_REQUIRE(d.Cs > 0 && d.Cs <= 64 && d.Cv > 0 && 2 * d.Cv <= 64 && d.Os > 0 && d.Os <= 128 && d.Os % 8 == 0 && d.Ov > 0 &&
                       d.Ov <= 64, SVNET_E_UNSUPPORTED, "svnet_edgeblock_bwd_f32: channel counts outside Cs<=64, 2Cv<=64, Os<=128 (mult of 8), Ov<=64");
     const int64_t E = d.B * d.N * d.k;

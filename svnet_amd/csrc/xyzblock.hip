@@ -83,15 +83,29 @@ __global__ __launch_bounds__(256) void xyzblock_fwd_kernel(XyzFwdArgs fa) {
     double sy1 = 0.0, sy2 = 0.0, sv1 = 0.0, sv2 = 0.0;
     float gsum[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
+    // neighbour ids: lane t of one coalesced load holds idx[p][t] (k <= 64), handed to the scalar unit by v_readlane; the
+    // next point's ids and the next edge's coordinates are requested ahead, so no edge waits on two dependent loads
+    const int lk = min(lane, k - 1);
+    int jv_next = (p_begin < p_end) ? (int)d.idx[(b * N + p_begin) * k + lk] : 0;
     for (int p = p_begin; p < p_end; ++p) {
         const int64_t gp = b * N + p;
+        const int jv = jv_next;
+        if (p + 1 < p_end) jv_next = (int)d.idx[(gp + 1) * k + lk];
         const float xi[3] = {xb[p], xb[N + p], xb[2 * N + p]};
         float ymax = -FLT_MAX, ymin = FLT_MAX;
         int smax = 0, smin = 0;
         float av[3] = {0.f, 0.f, 0.f}, avn[3] = {0.f, 0.f, 0.f};
+        float xn[3];
+        {
+            const int j0 = __builtin_amdgcn_readlane(jv, 0);
+            xn[0] = xb[j0]; xn[1] = xb[N + j0]; xn[2] = xb[2 * N + j0];
+        }
         for (int t = 0; t < k; ++t) {
-            const int64_t j = d.idx[gp * k + t];
-            const float xj[3] = {xb[j], xb[N + j], xb[2 * N + j]};
+            const float xj[3] = {xn[0], xn[1], xn[2]};
+            if (t + 1 < k) {
+                const int j1 = __builtin_amdgcn_readlane(jv, t + 1);
+                xn[0] = xb[j1]; xn[1] = xb[N + j1]; xn[2] = xb[2 * N + j1];
+            }
             EdgeFeat e;
             edge_features(xi, xj, w0, wz, e);
 #pragma unroll
@@ -268,15 +282,27 @@ __global__ __launch_bounds__(256) void xyzblock_bwd_kernel(svnet_xyzblock_bwd_de
     float m00 = 0.f, m01 = 0.f, m11 = 0.f;     // per lane (output channel o)
     float q00 = 0.f, q01 = 0.f, q11 = 0.f;     // wave-uniform sums of Q_e (for the gate-constant term)
 
+    const int lk = min(lane, k - 1);        // neighbour ids through v_readlane, next edge's coordinates ahead (see the forward)
+    int jv_next = (p_begin < p_end) ? (int)d.idx[(b * N + p_begin) * k + lk] : 0;
     for (int p = p_begin; p < p_end; ++p) {
         const int64_t gp = b * N + p;
+        const int jv = jv_next;
+        if (p + 1 < p_end) jv_next = (int)d.idx[(gp + 1) * k + lk];
         const float xi[3] = {xb[p], xb[N + p], xb[2 * N + p]};
         const int slot = (a1 >= 0.f) ? d.slot_max[gp * Os + lo] : d.slot_min[gp * Os + lo];
         const float gyv = d.gy[gp * Os + lo];
         const float gv0 = d.gv[(gp * 3 + 0) * Ov + lv] * gt, gv1 = d.gv[(gp * 3 + 1) * Ov + lv] * gt, gv2 = d.gv[(gp * 3 + 2) * Ov + lv] * gt;
+        float xn[3];
+        {
+            const int j0 = __builtin_amdgcn_readlane(jv, 0);
+            xn[0] = xb[j0]; xn[1] = xb[N + j0]; xn[2] = xb[2 * N + j0];
+        }
         for (int t = 0; t < k; ++t) {
-            const int64_t j = d.idx[gp * k + t];
-            const float xj[3] = {xb[j], xb[N + j], xb[2 * N + j]};
+            const float xj[3] = {xn[0], xn[1], xn[2]};
+            if (t + 1 < k) {
+                const int j1 = __builtin_amdgcn_readlane(jv, t + 1);
+                xn[0] = xb[j1]; xn[1] = xb[N + j1]; xn[2] = xb[2 * N + j1];
+            }
             EdgeFeat e;
             edge_features(xi, xj, w0, wz, e);
             // ---- scalar path
@@ -367,7 +393,7 @@ extern "C" int svnet_xyzblock_fwd_f32(const svnet_xyzblock_desc* desc, void* str
     SVNET_REQUIRE(d.x && d.idx && d.w0 && d.wz && d.w1 && d.w2 && d.y_max && d.y_min && d.slot_max && d.slot_min && d.mv && d.mvn &&
                       d.gate_sum, SVNET_E_ARG, "svnet_xyzblock_fwd_f32: null pointer");
     SVNET_REQUIRE((d.stat_y == nullptr) == (d.stat_v == nullptr), SVNET_E_ARG, "svnet_xyzblock_fwd_f32: pass both stat buffers or none");
-    SVNET_REQUIRE(d.B >= 0 && d.N > 0 && d.k > 0 && d.k <= 255, SVNET_E_ARG, "svnet_xyzblock_fwd_f32: bad sizes");
+    SVNET_REQUIRE(d.B >= 0 && d.N > 0 && d.k > 0 && d.k <= 64, SVNET_E_ARG, "svnet_xyzblock_fwd_f32: bad sizes (k <= 64)");
     SVNET_REQUIRE(d.Os > 0 && d.Os <= 64 && d.Ov > 0 && d.Ov <= 64, SVNET_E_UNSUPPORTED, "svnet_xyzblock_fwd_f32: needs Os <= 64, Ov <= 64");
     if (d.B == 0) return SVNET_OK;
     XyzFwdArgs fa;
@@ -426,7 +452,7 @@ extern "C" int svnet_xyzblock_bwd_f32(const svnet_xyzblock_bwd_desc* desc, void*
     const svnet_xyzblock_bwd_desc& d = *desc;
     SVNET_REQUIRE(d.x && d.idx && d.w0 && d.wz && d.w1 && d.w2 && d.slot_max && d.slot_min && d.coef && d.bcoef && d.gate && d.gy && d.gv &&
                       d.gconst && d.gw, SVNET_E_ARG, "svnet_xyzblock_bwd_f32: null pointer");
-    SVNET_REQUIRE(d.B >= 0 && d.N > 0 && d.k > 0 && d.k <= 255, SVNET_E_ARG, "svnet_xyzblock_bwd_f32: bad sizes");
+    SVNET_REQUIRE(d.B >= 0 && d.N > 0 && d.k > 0 && d.k <= 64, SVNET_E_ARG, "svnet_xyzblock_bwd_f32: bad sizes (k <= 64)");
     SVNET_REQUIRE(d.Os > 0 && d.Os <= 64 && d.Ov > 0 && d.Ov <= 64, SVNET_E_UNSUPPORTED, "svnet_xyzblock_bwd_f32: needs Os <= 64, Ov <= 64");
     if (d.B == 0) return SVNET_OK;
     int wpc = (int)svnet_cdiv(4096, d.B);                       // ~4096 waves = 1024 workgroups, one flush each

@@ -260,7 +260,7 @@ class SVBlock(nn.Module):
         if not (lin1.bw and lin1.ba and lin2.bw and self.v2s.linear.bw) or edges.idx_is_global:
             return False
         Cs, Cv = edges.s.shape[-1], edges.v.shape[-1]
-        return (Cs <= 64 and 2 * Cv <= 64 and lin1.out_features <= 128 and lin2.out_features <= 64 and edges.k <= 255
+        return (Cs <= 64 and 2 * Cv <= 64 and lin1.out_features <= 128 and lin2.out_features <= 64 and edges.k <= 64
                 and edges.s.shape[1] <= 8192 and lin1.out_features % 8 == 0 and lin1.in_features == 2 * Cs + 6 * Cv and self.bn1.track_running_stats and self.bn2.bn.track_running_stats)
 
     def forward(self, x):
@@ -274,7 +274,7 @@ class SVBlock(nn.Module):
             s, v = x
             lin1, lin2 = self.linear1, self.linear2
             if (isinstance(s, LazyInitScalar) and s.edges is v and not (lin1.bw or lin1.ba or lin2.bw or self.v2s.linear.bw)
-                    and lin1.in_features == 12 and lin1.out_features <= 64 and lin2.out_features <= 64 and v.k <= 255
+                    and lin1.in_features == 12 and lin1.out_features <= 64 and lin2.out_features <= 64 and v.k <= 64
                     and (self.training or not torch.is_grad_enabled()
                          or not any(p.requires_grad for p in self.parameters()))):
                 return PendingXyzBlock(self, s, v)
