@@ -176,7 +176,7 @@ typedef struct svnet_edgeblock_bwd_desc {
     const float* coef;           /* from svnet_edgeblock_coeffs_f32 */
     const float* gate;           /* [B,Ov] */
     const float* gy;             /* [P,Os] from the prelude */
-    const float* bcoef;          /* [3*Os + 2*Ov] from svnet_edgeblock_bwd_coeffs_f32 */
+    const float* bcoef;          /* [8*Os + 2*Ov + 4] from svnet_edgeblock_bwd_coeffs_f32 (with scale1) */
     const float* gv;             /* upstream gradient of v_out [P,3,Ov] */
     const float* gconst;         /* [B,2Cs]: dL/d(gate input) / (N*k) */
     float* dn_out; uint32_t* x_sign32; uint32_t* x_nz32;
@@ -192,10 +192,12 @@ int svnet_edgeblock_bwd_prelude_f32(const float* gs, const float* gv, const int3
                                     const float* mv, const float* mvn, const float* coef, const float* scale1,
                                     const float* gate, int64_t P, int64_t N, int64_t Os, int64_t Ov, float slope,
                                     float* gy, float* red, float* redv, float* dgate, void* stream);
-/* bcoef = [m1 | m2 | cs | c0 | c1]; BatchNorm parameter gradients are written to dgamma*, dbeta*.                   */
+/* bcoef = [m1 | m2 | cs (Os each) | c0 | c1 (Ov each)], and when scale1 != NULL (binarized layer), from the next multiple of
+ * 4 floats on, the tile kernel's per-channel table [cs | alpha | beta | scale | pooled-is-max] (5*Os): allocate
+ * 8*Os + 2*Ov + 4 floats.  BatchNorm parameter gradients are written to dgamma*, dbeta*.                              */
 int svnet_edgeblock_bwd_coeffs_f32(const float* red, const float* redv, const float* coef, const float* gamma1,
-                                   const float* gamma2, int64_t E, int64_t Os, int64_t Ov, int training, float* bcoef,
-                                   float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, void* stream);
+                                   const float* gamma2, int64_t E, int64_t Os, int64_t Ov, int training, const float* scale1,
+                                   float* bcoef, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, void* stream);
 int svnet_edgeblock_bwd_f32(const svnet_edgeblock_bwd_desc* desc, void* stream);
 /* Reverse neighbour lists of a kNN graph (idx [B*N,k], cloud-local ids): the edges e = i*k + t that point at j are
  * rev_edge[rev_range[2j] .. rev_range[2j+1]).  rev_range [2*B*N], rev_edge [B*N*k]; N <= 8192; ids outside [0,N) are skipped. */

@@ -122,7 +122,7 @@ SIGNATURES = {
     "svnet_edgeblock_apply_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p]),
     "svnet_edgeblock_wbt_bf16": (c_int, [c_p, c_p, c_i64, c_p, c_p]),
     "svnet_edgeblock_bwd_prelude_f32": (c_int, [c_p] * 9 + [c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p, c_p, c_p]),
-    "svnet_edgeblock_bwd_coeffs_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "svnet_edgeblock_bwd_coeffs_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "svnet_edgeblock_bwd_f32": (c_int, [ctypes.POINTER(EdgeBlockBwdDesc), c_p]),
     "svnet_xyzblock_fwd_f32": (c_int, [ctypes.POINTER(XyzBlockDesc), c_p]),
     "svnet_xyzblock_coeffs_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_f, c_f, c_p, c_p, c_p, c_p]),

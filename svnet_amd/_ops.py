@@ -641,11 +641,11 @@ class EdgeBlock(torch.autograd.Function):
         gy = torch.empty((P, Os), **f32)
         call("svnet_edgeblock_bwd_prelude_f32", _p(gs), _p(gv), _p(n_max), _p(n_min), _p(mv), _p(mvn), _p(coef), _p(sc1), _p(gate),
              P, N, Os, Ov, 0.2, _p(gy), _p(red), _p(redv), _p(dgate), _stream())
-        bcoef = torch.empty((3 * Os + 2 * Ov,), **f32)
+        bcoef = torch.empty((8 * Os + 2 * Ov + 4,), **f32)
         dg1, db1 = torch.empty((Os,), **f32), torch.empty((Os,), **f32)
         dg2, db2 = torch.empty((Ov,), **f32), torch.empty((Ov,), **f32)
-        call("svnet_edgeblock_bwd_coeffs_f32", _p(red), _p(redv), _p(coef), _p(g1), _p(g2), E, Os, Ov, int(training), _p(bcoef), _p(dg1),
-             _p(db1), _p(dg2), _p(db2), _stream())
+        call("svnet_edgeblock_bwd_coeffs_f32", _p(red), _p(redv), _p(coef), _p(g1), _p(g2), E, Os, Ov, int(training), _p(sc1), _p(bcoef),
+             _p(dg1), _p(db1), _p(dg2), _p(db2), _stream())
 
         # ---- gate MLP backward: dW0, dW2 and the per-edge constant of the gate path, one workgroup per cloud
         gconst = torch.empty((B, 2 * Cs), **f32)
@@ -780,8 +780,8 @@ class XyzBlock(torch.autograd.Function):
         bcoef = torch.empty((3 * Os + 2 * Ov,), **f32)
         dg1, db1 = torch.empty((Os,), **f32), torch.empty((Os,), **f32)
         dg2, db2 = torch.empty((Ov,), **f32), torch.empty((Ov,), **f32)
-        call("svnet_edgeblock_bwd_coeffs_f32", _p(red), _p(redv), _p(coef), _p(g1), _p(g2), E, Os, Ov, int(training), _p(bcoef), _p(dg1),
-             _p(db1), _p(dg2), _p(db2), _stream())
+        call("svnet_edgeblock_bwd_coeffs_f32", _p(red), _p(redv), _p(coef), _p(g1), _p(g2), E, Os, Ov, int(training), None, _p(bcoef),
+             _p(dg1), _p(db1), _p(dg2), _p(db2), _stream())
         # gate MLP backward
         gconst = torch.empty((B, 6), **f32)
         inv_nk = 1.0 / float(N * k)

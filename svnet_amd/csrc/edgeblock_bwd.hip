@@ -82,6 +82,11 @@ __device__ __forceinline__ float fold16(float a, float b) {
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+// value held by lane (l ^ 32)
+__device__ __forceinline__ uint32_t lane_half_swap(uint32_t x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return (threadIdx.x & 32) ? r[0] : r[1];
+}
 // Eight wave-wide sums in 18 VALU instructions: every lane of the 8-lane group g = lane >> 3 ends up with the sum over the
 // wave of s[bitreverse3(g)]  (groups 0..7 hold s0, s4, s2, s6, s1, s5, s3, s7).
 __device__ __forceinline__ float wave_sum8_packed(const float (&s)[8], int lane) {
@@ -129,17 +134,28 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_prelude_kernel(
 // bcoef = [m1 | m2 | cs (Os each) | c0 | c1 (Ov each)];  BN parameter gradients written (not accumulated).
 __global__ void edgeblock_bwd_coeffs_kernel(const float* __restrict__ red, const float* __restrict__ redv, const float* __restrict__ coef,
                                             const float* __restrict__ g1, const float* __restrict__ g2, int64_t E, int Os, int Ov,
-                                            int training, float* __restrict__ bcoef, float* __restrict__ dg1, float* __restrict__ db1,
-                                            float* __restrict__ dg2, float* __restrict__ db2) {
+                                            int training, const float* __restrict__ scale1, float* __restrict__ bcoef,
+                                            float* __restrict__ dg1, float* __restrict__ db1, float* __restrict__ dg2,
+                                            float* __restrict__ db2) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const float invE = 1.f / (float)E;
     if (c < Os) {
         const float iy = coef[3 * Os + c];
-        bcoef[c] = training ? red[c] * invE : 0.f;
-        bcoef[Os + c] = training ? red[Os + c] * invE : 0.f;
-        bcoef[2 * Os + c] = g1[c] * iy;
+        const float m1 = training ? red[c] * invE : 0.f, m2 = training ? red[Os + c] * invE : 0.f, cs = g1[c] * iy;
+        bcoef[c] = m1;
+        bcoef[Os + c] = m2;
+        bcoef[2 * Os + c] = cs;
         dg1[c] = red[Os + c];
         db1[c] = red[c];
+        if (scale1) {   // per-channel constants of the binarized tile kernel: dy_pre = cs*g - (alpha + beta*n); pooled edge = arg-max / arg-min
+            float* chc = bcoef + ((3 * Os + 2 * Ov + 3) & ~3);     // 16-byte aligned for the float4 reads of the tile kernel
+            const float sc = scale1[c], my = coef[2 * Os + c];
+            chc[c] = cs;
+            chc[Os + c] = cs * (m1 - my * iy * m2);
+            chc[2 * Os + c] = cs * sc * iy * m2;
+            chc[3 * Os + c] = sc;
+            chc[4 * Os + c] = coef[c] >= 0.f ? 1.f : 0.f;
+        }
     }
     if (c < Ov) {
         const float* Avp = coef + 4 * Os;
@@ -337,7 +353,6 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
     float* dnl = dxl;                                                // [TE][DNS]   dL/dn = dy_pre*scale   (phases A -> B), ALIASES dxl:
                                                                      //             phase B pulls it into registers before writing dxl
     uint64_t* pl = reinterpret_cast<uint64_t*>(dxl + TE * DXS);      // [3][TE][NW] sign | nz | ste (row-major words)
-    float* chc = reinterpret_cast<float*>(pl + 3 * TE * NW);         // [5][Os]     per-channel constants of phase A
 
     PHASE_INIT();
     const int tid = threadIdx.x, lane = tid & 63;
@@ -386,16 +401,6 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
     //   dy_pre = cs*(g - m1 - xhat*m2), xhat = (scale*n - mean)*invstd, g = gy[p,o] on the pooled edge, else 0
     //          = cs*g - (alpha + beta*n)
     {
-        const float* A1 = d.coef; const float* MY = d.coef + 2 * Os; const float* IY = d.coef + 3 * Os;
-        const float* M1 = d.bcoef; const float* M2 = d.bcoef + Os; const float* CS = d.bcoef + 2 * Os;
-        for (int o = tid; o < Os; o += 256) {
-            const float cs = CS[o], sc = d.scale1[o], iy = IY[o];
-            chc[o] = cs;
-            chc[Os + o] = cs * (M1[o] - MY[o] * iy * M2[o]);     // alpha
-            chc[2 * Os + o] = cs * sc * iy * M2[o];               // beta
-            chc[3 * Os + o] = sc;
-            chc[4 * Os + o] = A1[o] >= 0.f ? 1.f : 0.f;           // the pooled edge is the arg-max (A1 >= 0) or the arg-min
-        }
         // ternary / STE planes of the tile: [e][plane][word] in HBM -> [plane][row][word] in LDS
         for (int item = tid; item < TE * 3 * NW; item += 256) {
             const int r = item / (3 * NW), q = item - r * (3 * NW);
@@ -405,6 +410,15 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
         // this thread's edge-channel quads (<= 4: Os <= 128): their loads go out before the barrier, with the constants'
         const int O4 = Os >> 2;
         const int k = (int)d.k;
+        // per-channel constants [cs | alpha | beta | scale | pooled-is-max] from svnet_edgeblock_bwd_coeffs_f32.  256 is a multiple
+        // of Os/4 (Os in {32, 64, 128}: asserted on the host), so a thread's quads all sit on the same four channels
+        const float* chc = d.bcoef + ((3 * Os + 2 * d.Ov + 3) & ~3);
+        const int o4c = (tid % (Os >> 2)) << 2;
+        const float4 cs = *reinterpret_cast<const float4*>(chc + o4c);
+        const float4 al = *reinterpret_cast<const float4*>(chc + Os + o4c);
+        const float4 be = *reinterpret_cast<const float4*>(chc + 2 * Os + o4c);
+        const float4 sc = *reinterpret_cast<const float4*>(chc + 3 * Os + o4c);
+        const float4 ps = *reinterpret_cast<const float4*>(chc + 4 * Os + o4c);
         constexpr int NI = NKS / 2;       // TE * (Os / 4) / 256 quads per thread
         short4 n4[NI]; float4 gy4[NI]; uchar4 smx[NI], smn[NI]; int tt[NI];
 #pragma unroll
@@ -432,11 +446,6 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
             const int t = tt[it];
             float4 dn = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t >= 0) {
-                const float4 cs = *reinterpret_cast<const float4*>(chc + o4);
-                const float4 al = *reinterpret_cast<const float4*>(chc + Os + o4);
-                const float4 be = *reinterpret_cast<const float4*>(chc + 2 * Os + o4);
-                const float4 sc = *reinterpret_cast<const float4*>(chc + 3 * Os + o4);
-                const float4 ps = *reinterpret_cast<const float4*>(chc + 4 * Os + o4);
                 const float g0 = ((ps.x != 0.f ? smx[it].x : smn[it].x) == t) ? gy4[it].x : 0.f;
                 const float g1 = ((ps.y != 0.f ? smx[it].y : smn[it].y) == t) ? gy4[it].y : 0.f;
                 const float g2 = ((ps.z != 0.f ? smx[it].z : smn[it].z) == t) ? gy4[it].z : 0.f;
@@ -511,12 +520,17 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
             const int ct = wave + 4 * q;
             if (ct < NCOL / 32) {
                 const int col = ct * 32 + r;
+                float csum = 0.f;                       // dL/dbeta of this column: sum over the tile's rows (rows past E are zero)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
                     const uint64_t st = pl[(2 * TE + row) * NW + (col >> 6)];
-                    dxl[row * DXS + col] = ((st >> (col & 63)) & 1ull) ? acc[q][i] : 0.f;
+                    const float v = ((st >> (col & 63)) & 1ull) ? acc[q][i] : 0.f;
+                    dxl[row * DXS + col] = v;
+                    csum += v;
                 }
+                const float other = __uint_as_float(lane_half_swap(__float_as_uint(csum)));
+                if (h == 0) { const float t = csum + other; if (t != 0.f) ATOMIC_ADD(&d.dbeta_perm[col], t); }
             }
         }
     }
@@ -549,23 +563,24 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
             const int cw_shift = Cs <= 32 ? 5 : 6;                        // threads = (row group, channel): shifts, no divisions
             const int c = tid & ((1 << cw_shift) - 1), rg = tid >> cw_shift, RG = 256 >> cw_shift;
             if (c < Cs) {
+                // gate-path constants of the tile's (first) cloud: loaded once, re-read only where a tile straddles two clouds
+                int gc_cur = row_gc[0];
+                float g0c = d.gconst[gc_cur + c], g1c = d.gconst[gc_cur + Cs + c];
                 for (int r = rg; r < TE; r += RG) {
                     const int slot = row_slot[r];
                     if (slot < 0) continue;
-                    const float* gcb = d.gconst + row_gc[r];
-                    const float d0 = dxl[r * DXS + c] + gcb[c];
+                    if (row_gc[r] != gc_cur) {
+                        gc_cur = row_gc[r];
+                        g0c = d.gconst[gc_cur + c];
+                        g1c = d.gconst[gc_cur + Cs + c];
+                    }
+                    const float d0 = dxl[r * DXS + c] + g0c;
                     d.msg[(e0 + r) * R + c] = d0;
-                    const float cen = (dxl[r * DXS + 64 + c] + gcb[Cs + c]) - d0;
+                    const float cen = (dxl[r * DXS + 64 + c] + g1c) - d0;
                     if (use_lds) atomicAdd(&csl[slot * Cs + c], cen);
                     else ATOMIC_ADD(&d.ds_acc[(gp_first + slot) * Cs + c], cen);
                 }
             }
-        }
-        for (int col = tid; col < NCOL; col += 256) {                     // rows past E hold zeros
-            float sum = 0.f;
-#pragma unroll 8
-            for (int r = 0; r < TE; ++r) sum += dxl[r * DXS + col];
-            if (sum != 0.f) ATOMIC_ADD(&d.dbeta_perm[col], sum);
         }
         __syncthreads();
         if (use_lds)
@@ -682,13 +697,13 @@ extern "C" int svnet_edgeblock_bwd_prelude_f32(const float* gs, const float* gv,
 }
 
 extern "C" int svnet_edgeblock_bwd_coeffs_f32(const float* red, const float* redv, const float* coef, const float* gamma1,
-                                              const float* gamma2, int64_t E, int64_t Os, int64_t Ov, int training, float* bcoef,
-                                              float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, void* stream) {
+                                              const float* gamma2, int64_t E, int64_t Os, int64_t Ov, int training, const float* scale1,
+                                              float* bcoef, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, void* stream) {
     SVNET_REQUIRE(red && redv && coef && gamma1 && gamma2 && bcoef && dgamma1 && dbeta1 && dgamma2 && dbeta2 && E > 0, SVNET_E_ARG,
                   "svnet_edgeblock_bwd_coeffs_f32: bad arguments");
     const int64_t n = Os > Ov ? Os : Ov;
     hipLaunchKernelGGL(edgeblock_bwd_coeffs_kernel, dim3((unsigned)svnet_cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream, red, redv, coef,
-                       gamma1, gamma2, E, (int)Os, (int)Ov, training, bcoef, dgamma1, dbeta1, dgamma2, dbeta2);
+                       gamma1, gamma2, E, (int)Os, (int)Ov, training, scale1, bcoef, dgamma1, dbeta1, dgamma2, dbeta2);
     SVNET_CHECK_LAUNCH("edgeblock_bwd_coeffs_kernel");
     return SVNET_OK;
 }
@@ -701,6 +716,7 @@ extern "C" int svnet_edgeblock_bwd_f32(const svnet_edgeblock_bwd_desc* desc, voi
                       d.msg && d.dvc && d.dzc && d.dbeta_perm,
                   SVNET_E_ARG, "svnet_edgeblock_bwd_f32: null pointer");
     SVNET_REQUIRE(d.B >= 0 && d.N > 0 && d.k > 0 && d.k <= 64, SVNET_E_ARG, "svnet_edgeblock_bwd_f32: bad sizes (k <= 64)");
+    SVNET_REQUIRE((d.Os & (d.Os - 1)) == 0, SVNET_E_UNSUPPORTED, "svnet_edgeblock_bwd_f32: Os must be a power of two (8..128)");
     SVNET_REQUIRE(d.Cs > 0 && d.Cs <= 64 && d.Cv > 0 && 2 * d.Cv <= 64 && d.Os > 0 && d.Os <= 128 && d.Os % 8 == 0 && d.Ov > 0 &&
                       d.Ov <= 64, SVNET_E_UNSUPPORTED, "svnet_edgeblock_bwd_f32: channel counts outside Cs<=64, 2Cv<=64, Os<=128 (mult of 8), Ov<=64");
     const int64_t E = d.B * d.N * d.k;
@@ -726,7 +742,7 @@ extern "C" int svnet_edgeblock_bwd_f32(const svnet_edgeblock_bwd_desc* desc, voi
     if (!do_tile) return SVNET_OK;
 
     // scalar path: 32-edge tiles
-    const size_t lds = (size_t)TE * DXS * 4 + (size_t)3 * TE * NW * 8 + (size_t)5 * d.Os * 4;   // dnl aliases dxl
+    const size_t lds = (size_t)TE * DXS * 4 + (size_t)3 * TE * NW * 8;   // dnl aliases dxl
     const unsigned grid = (unsigned)svnet_cdiv(E, TE);
 #define SVNET_LAUNCH_BWD(MODE)                                                                                              \
     do {                                                                                                                    \
