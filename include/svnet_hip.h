@@ -89,7 +89,10 @@ typedef struct svnet_gemm_desc {
     float* col_sum;
     int split_k;       /* 0 = choose automatically (vector-ALU kernel only) */
     int accumulate;    /* C += result */
+    void* workspace;   /* optional scratch; with b_exact, >= svnet_gemm_workspace_bytes(N, K) lets the MFMA path pack B once as */
+    size_t workspace_bytes; /* bf16 [N][K] (k contiguous) so that its LDS staging is plain 16-byte copies                       */
 } svnet_gemm_desc;
+size_t svnet_gemm_workspace_bytes(int64_t N, int64_t K);
 int svnet_gemm_f32(const svnet_gemm_desc* desc, void* stream);
 
 /* ------------------------------------------------------------------ binarized layers (sv_layers.py:20-53 Linear, :55-78 Conv1d)

@@ -35,6 +35,8 @@ class GemmDesc(ctypes.Structure):
         ("col_sum", c_p),
         ("split_k", c_int),
         ("accumulate", c_int),
+        ("workspace", c_p),
+        ("workspace_bytes", ctypes.c_size_t),
     ]
 
 
@@ -107,6 +109,7 @@ SIGNATURES = {
     "svnet_edge_xyz_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_int, c_p, c_p]),
     "svnet_edge_diffcat_fwd_f32": (c_int, [c_p, c_p, c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
     "svnet_edge_diffcat_bwd_f32": (c_int, [c_p, c_p, c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
+    "svnet_gemm_workspace_bytes": (ctypes.c_size_t, [c_i64, c_i64]),
     "svnet_gemm_f32": (c_int, [ctypes.POINTER(GemmDesc), c_p]),
     "svnet_binweight_prepare_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),
     "svnet_binlinear_fwd_f32": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),

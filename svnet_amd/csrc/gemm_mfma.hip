@@ -65,7 +65,24 @@ struct RowsArgs {
     float* col_sum;
     int accumulate;
     int a_vec;              // A rows are 16-byte aligned and lda % 4 == 0: fragment loads as 2 x dwordx4
+    const uint16_t* B16;    // optional: B packed as bf16 [round32(N)][Kp] (k contiguous, zero padded), Kp = round16(K)
+    int Kp;
 };
+
+// B (any strides, values exact in bf16) -> bf16 [Np][Kp], zero padded
+__global__ void pack_b_bf16_kernel(const float* __restrict__ B, int64_t b_rs, int64_t b_cs, int K, int N, int Kp, int Np,
+                                   uint16_t* __restrict__ out) {
+    const int total = Np * Kp;
+    // consecutive threads walk n for a fixed k when B is n-contiguous, k otherwise: coalesced reads either way
+    const bool n_fast = b_cs == 1;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        int n, k;
+        if (n_fast) { n = e % Np; k = e / Np; } else { k = e % Kp; n = e / Kp; }
+        float v = 0.f;
+        if (n < N && k < K) v = B[(int64_t)k * b_rs + (int64_t)n * b_cs];
+        out[(int64_t)n * Kp + k] = (uint16_t)(__float_as_uint(v) >> 16);
+    }
+}
 
 constexpr int KC = 128;         // K chunk staged in LDS
 constexpr int LDS_STRIDE = KC + 8;  // bf16 elements per LDS row: (KC/8 + 1) 16-byte slots, odd -> conflict-free b128 reads
@@ -120,7 +137,14 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_kernel(RowsArgs a) {
                 __syncthreads();  // previous readers of Bt are done
                 // stage B[k0 : k0+kc, n0 : n0+NT*32] as bf16 [n][k]: one 16-byte LDS store per 8 consecutive k
                 const int pieces = NT * 32 * (kc16 >> 3);
-                if (a.b_rs == 1) {            // k contiguous in memory: consecutive threads walk k
+                if (a.B16) {                  // pre-packed bf16 [n][k]: plain 16-byte copies, all in flight together
+                    const int kp = kc16 >> 3;
+                    for (int e = tid; e < pieces; e += 256) {
+                        const int n = e / kp, k8 = (e - n * kp) << 3;
+                        *reinterpret_cast<uint4*>(&Bt[n * LDS_STRIDE + k8]) =
+                            *reinterpret_cast<const uint4*>(a.B16 + (int64_t)(n0 + n) * a.Kp + k0 + k8);
+                    }
+                } else if (a.b_rs == 1) {     // k contiguous in memory: consecutive threads walk k
                     const int kp = kc16 >> 3;
                     for (int e = tid; e < pieces; e += 256) {
                         const int n = e / kp, k8 = (e - n * kp) << 3;
@@ -497,6 +521,12 @@ void launch_tn(TnArgs a, hipStream_t st) {
 
 }  // namespace
 
+extern "C" size_t svnet_gemm_workspace_bytes(int64_t N, int64_t K) {
+    if (N <= 0 || K <= 0) return 0;
+    const int64_t tile = N <= 32 ? 32 : (N <= 64 ? 64 : (N <= 128 ? 128 : 256));     // widest column tile a workgroup may use
+    return (size_t)((N + tile - 1) / tile * tile) * (size_t)((K + 15) / 16 * 16) * 2;
+}
+
 // Internal entry points used by svnet_gemm_f32 (gemm.hip).
 int svnet_mfma_rows(const svnet_gemm_desc& d, hipStream_t st) {
     RowsArgs a;
@@ -507,6 +537,16 @@ int svnet_mfma_rows(const svnet_gemm_desc& d, hipStream_t st) {
     a.alpha = d.alpha; a.col_scale = d.col_scale; a.bias = d.bias;
     a.mask = d.mask; a.col_sum = d.col_sum; a.accumulate = d.accumulate;
     a.a_vec = (d.a_rs % 4 == 0) && (reinterpret_cast<uintptr_t>(d.A) % 16 == 0);
+    a.B16 = nullptr; a.Kp = 0;
+    const int cpb = (d.N <= 32 || d.M <= 512) ? 32 : (d.N <= 64 ? 64 : (d.N <= 128 ? 128 : 256));   // columns per workgroup (NT * 32)
+    if (d.workspace && d.workspace_bytes >= svnet_gemm_workspace_bytes(d.N, d.K) && reinterpret_cast<uintptr_t>(d.workspace) % 16 == 0) {
+        const int Kp = (int)((d.K + 15) / 16 * 16), Np = (int)((d.N + cpb - 1) / cpb * cpb);
+        uint16_t* w = reinterpret_cast<uint16_t*>(d.workspace);
+        hipLaunchKernelGGL(pack_b_bf16_kernel, dim3(svnet_grid((int64_t)Kp * Np, 256)), dim3(256), 0, st, d.B, d.b_rs, d.b_cs, (int)d.K,
+                           (int)d.N, Kp, Np, w);
+        SVNET_CHECK_LAUNCH("pack_b_bf16_kernel");
+        a.B16 = w; a.Kp = Kp;
+    }
     // few row blocks (the classifier head: M = batch): narrow column tiles so that the grid still has tens of workgroups
     if (d.N <= 32 || d.M <= 512) launch_rows<1>(a, st);
     else if (d.N <= 64) launch_rows<2>(a, st);
