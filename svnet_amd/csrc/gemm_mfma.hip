@@ -267,55 +267,48 @@ __global__ __launch_bounds__(256, 2) void mfma_tn_kernel(TnArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-    for (int64_t m64 = mb; m64 < me; m64 += 64) {
-        uint64_t wsg[NQ], wnz[NQ];
-        if (BMODE == 1) {
+    // fp32 x fp32 (BMODE 0 is the only mode left here; ternary B runs in mfma_tn_tern_kernel).  The A fragment and the NQ B
+    // fragments of the next 16-row step are requested before the MFMAs of the current one.
+    {
+        const int64_t mlast = a.M - 1;
+        const int pc = min(p, a.P - 1);
+        int qc[NQ];
 #pragma unroll
-            for (int t = 0; t < NQ; ++t) {
-                const int q = q0 + t * 32 + r;
-                const bool ok = q < a.Q;
-                wsg[t] = ok ? a.b_sign[(m64 >> 6) * a.Q + q] : 0ull;
-                wnz[t] = ok ? a.b_nz[(m64 >> 6) * a.Q + q] : 0ull;
+        for (int t = 0; t < NQ; ++t) qc[t] = min(q0 + t * 32 + r, a.Q - 1);
+        float xn[8], yn[NQ][8];
+#define SVNET_TN0_LOAD(MROW)                                                                                  \
+    do {                                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                        \
+            const int64_t row_ = min((MROW) + j, mlast);                                                      \
+            xn[j] = a.A[row_ * a.lda + pc];                                                                   \
+            _Pragma("unroll") for (int t = 0; t < NQ; ++t) yn[t][j] = a.B[row_ * a.ldb + qc[t]];              \
+        }                                                                                                     \
+    } while (0)
+        if (mb < me) SVNET_TN0_LOAD(mb + 8 * h);
+        for (int64_t m16 = mb; m16 < me; m16 += 16) {
+            float x[8], y[NQ][8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool ok = m16 + 8 * h + j < me;            // rows of the next sub-range are not mine
+                x[j] = (ok && p_ok) ? xn[j] : 0.f;
+#pragma unroll
+                for (int t = 0; t < NQ; ++t) y[t][j] = ok ? yn[t][j] : 0.f;
             }
-        }
-#pragma unroll
-        for (int s16 = 0; s16 < 64; s16 += 16) {
-            const int64_t mrow = m64 + s16 + 8 * h;
-            if (m64 + s16 >= me) break;  // wave-uniform
-            float x[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = (p_ok && mrow + j < me) ? a.A[(mrow + j) * a.lda + p] : 0.f;
+            if (m16 + 16 < me) SVNET_TN0_LOAD(m16 + 16 + 8 * h);
             const Split3 sa = split_frag(x);
 #pragma unroll
             for (int t = 0; t < NQ; ++t) {
                 if (q0 + t * 32 >= a.Q) break;  // uniform
-                if (BMODE == 1) {
-                    bf16x8 b;
-                    const int sh = s16 + 8 * h;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const uint32_t nzb = (uint32_t)(wnz[t] >> (sh + j)) & 1u;
-                        const uint32_t sgb = (uint32_t)(wsg[t] >> (sh + j)) & 1u;
-                        b[j] = bf16_from_bits(nzb ? (sgb ? 0x3F80u : 0xBF80u) : 0u);  // rows beyond M carry nz = 0
-                    }
-                    acc[t] = MFMA(sa.h, b, acc[t]);
-                    acc[t] = MFMA(sa.m, b, acc[t]);
-                    acc[t] = MFMA(sa.l, b, acc[t]);
-                } else {
-                    const int q = q0 + t * 32 + r;
-                    float y[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) y[j] = (q < a.Q && mrow + j < me) ? a.B[(mrow + j) * a.ldb + q] : 0.f;
-                    const Split3 sb = split_frag(y);
-                    acc[t] = MFMA(sa.h, sb.h, acc[t]);
-                    acc[t] = MFMA(sa.h, sb.m, acc[t]);
-                    acc[t] = MFMA(sa.m, sb.h, acc[t]);
-                    acc[t] = MFMA(sa.h, sb.l, acc[t]);
-                    acc[t] = MFMA(sa.l, sb.h, acc[t]);
-                    acc[t] = MFMA(sa.m, sb.m, acc[t]);
-                }
+                const Split3 sb = split_frag(y[t]);
+                acc[t] = MFMA(sa.h, sb.h, acc[t]);
+                acc[t] = MFMA(sa.h, sb.m, acc[t]);
+                acc[t] = MFMA(sa.m, sb.h, acc[t]);
+                acc[t] = MFMA(sa.h, sb.l, acc[t]);
+                acc[t] = MFMA(sa.l, sb.h, acc[t]);
+                acc[t] = MFMA(sa.m, sb.m, acc[t]);
             }
         }
+#undef SVNET_TN0_LOAD
     }
     // Waves that split the row range of one p tile (narrow P) first combine their partial tiles in LDS: the output
     // matrix is tiny and shared by the whole grid, and same-address float atomics serialise at the memory side.
@@ -573,7 +566,7 @@ int svnet_mfma_tn(const float* A, int64_t lda, const float* B, int64_t ldb, cons
     else if (Q <= 64) { if (tern) launch_tn<2, 1>(a, st); else launch_tn<2, 0>(a, st); }
     else if (Q <= 128) { if (tern) launch_tn<4, 1>(a, st); else launch_tn<4, 0>(a, st); }
     else if (Q <= 160 || Q == 320) { if (tern) launch_tn<5, 1>(a, st); else launch_tn<5, 0>(a, st); }   // 320 = fused edge block
-    else { if (tern) launch_tn<8, 1>(a, st); else launch_tn<8, 0>(a, st); }
+    else { if (tern) launch_tn<8, 1>(a, st); else launch_tn<4, 0>(a, st); }   // fp32 B: 128-column groups (register budget of the prefetch)
     SVNET_CHECK_LAUNCH("mfma_tn_kernel");
     return SVNET_OK;
 }
