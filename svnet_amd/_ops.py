@@ -55,7 +55,7 @@ def gemm(M, N, K, B, b_rs, b_cs, C, ldc, A=None, a_rs=0, a_cs=0, a_scale=None, a
     d.col_sum = _p(col_sum)
     d.split_k, d.accumulate = split_k, int(accumulate)
     ws = None
-    if b_exact and A is not None and M >= 8192:      # big tall-and-skinny product against sign weights: let the library pack B once
+    if b_exact and A is not None and M >= 8192 and K >= 128 and N >= 64:   # big product against sign weights: let the library pack B once
         nbytes = _lib.lib().svnet_gemm_workspace_bytes(N, K)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=C.device)
         d.workspace, d.workspace_bytes = _p(ws), nbytes

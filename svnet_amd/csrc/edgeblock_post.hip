@@ -152,22 +152,34 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_gather_kernel(const float* 
     int col[NCH];
 #pragma unroll
     for (int q = 0; q < NCH; ++q) col[q] = min(64 * q + lane, R - 1);     // clamped: lanes past the row re-read its last column
-    if (beg < end) {
-        const float* row = msg + (int64_t)rev_edge[beg] * R;
-#pragma unroll
-        for (int q = 0; q < NCH; ++q) nx[q] = row[col[q]];
-    }
-    for (int n = beg; n < end; ++n) {
-        float cur[NCH];
-#pragma unroll
-        for (int q = 0; q < NCH; ++q) cur[q] = nx[q];
-        if (n + 1 < end) {
-            const float* row = msg + (int64_t)rev_edge[n + 1] * R;
+    // the list's edge ids come in with one coalesced load per 64 entries (lane n holds entry n, handed to the scalar unit by
+    // v_readlane), so a row's loads never wait on a load of their own index; rows are requested two entries ahead
+    for (int base = beg; base < end; base += 64) {
+        const int cnt = min(64, end - base);
+        const int ev = rev_edge[base + min(lane, cnt - 1)];
+        float n2[NCH];
+        {
+            const float* row = msg + (int64_t)__builtin_amdgcn_readlane(ev, 0) * R;
 #pragma unroll
             for (int q = 0; q < NCH; ++q) nx[q] = row[col[q]];
         }
+        if (cnt > 1) {
+            const float* row = msg + (int64_t)__builtin_amdgcn_readlane(ev, 1) * R;
 #pragma unroll
-        for (int q = 0; q < NCH; ++q) acc[q] += cur[q];
+            for (int q = 0; q < NCH; ++q) n2[q] = row[col[q]];
+        }
+        for (int n = 0; n < cnt; ++n) {
+            float cur[NCH];
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) { cur[q] = nx[q]; nx[q] = n2[q]; }
+            if (n + 2 < cnt) {
+                const float* row = msg + (int64_t)__builtin_amdgcn_readlane(ev, n + 2) * R;
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) n2[q] = row[col[q]];
+            }
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) acc[q] += cur[q];
+        }
     }
     const int RW = 2 * Ov + 6;
     const int oV = Cs, oZ = oV + 3 * Cv, oU = oZ + 9;                 // msg row = [ds (Cs) | dve (3 Cv) | dz (9) | dv' (3 Ov) | pad]
