@@ -89,6 +89,8 @@ typedef struct svnet_gemm_desc {
     float* col_sum;
     int split_k;       /* 0 = choose automatically (vector-ALU kernel only) */
     int accumulate;    /* C += result */
+    uint32_t tern_tile_mask; /* ternary A only: bit t set = rows [32t, 32t+32) of A^T (output rows i) may be non-zero; 0 = all.
+                                Cleared tiles are skipped: their outputs are left untouched (use with accumulate on zeros)       */
     void* workspace;   /* optional scratch; with b_exact, >= svnet_gemm_workspace_bytes(N, K) lets the MFMA path pack B once as */
     size_t workspace_bytes; /* bf16 [N][K] (k contiguous) so that its LDS staging is plain 16-byte copies                       */
 } svnet_gemm_desc;

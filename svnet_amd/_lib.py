@@ -35,6 +35,7 @@ class GemmDesc(ctypes.Structure):
         ("col_sum", c_p),
         ("split_k", c_int),
         ("accumulate", c_int),
+        ("tern_tile_mask", ctypes.c_uint32),
         ("workspace", c_p),
         ("workspace_bytes", ctypes.c_size_t),
     ]

@@ -38,7 +38,7 @@ def _f32c(t):
 
 
 def gemm(M, N, K, B, b_rs, b_cs, C, ldc, A=None, a_rs=0, a_cs=0, a_scale=None, a_planes=None, b_exact=False, c_cs=1,
-         alpha=1.0, col_scale=None, bias=None, mask=None, col_sum=None, split_k=0, accumulate=False):
+         alpha=1.0, col_scale=None, bias=None, mask=None, col_sum=None, split_k=0, accumulate=False, tern_tile_mask=0):
     """C(i,j) = epilogue(sum_k A(i,k) B(k,j)); see svnet_gemm_desc (bit-planes are row-sliced)."""
     d = GemmDesc()
     d.M, d.N, d.K = M, N, K
@@ -54,6 +54,7 @@ def gemm(M, N, K, B, b_rs, b_cs, C, ldc, A=None, a_rs=0, a_cs=0, a_scale=None, a
     d.mask = _p(mask)
     d.col_sum = _p(col_sum)
     d.split_k, d.accumulate = split_k, int(accumulate)
+    d.tern_tile_mask = tern_tile_mask
     ws = None
     if b_exact and A is not None and M >= 8192 and K >= 128 and N >= 64:   # big product against sign weights: let the library pack B once
         nbytes = _lib.lib().svnet_gemm_workspace_bytes(N, K)
@@ -698,7 +699,12 @@ class EdgeBlock(torch.autograd.Function):
         # linear1's weight-gradient product GXp = dy^T . x_b (MFMA, ternary planes, fused column order) only needs the tile
         # kernel's outputs: it keeps the main stream while the side stream (joined with main first) sums the messages
         side.wait_stream(main)
-        gemm(320, Os, E, a_planes=(x_sign, x_nz), B=dn_out, b_rs=Os, b_cs=1, C=GXp, ldc=1, c_cs=320, accumulate=True)
+        used = 0                      # 32-column tiles of the 5 x 64 fused columns that hold features (the rest is padding)
+        for ct in range(10):
+            if ((Cs if ct < 4 else 2 * Cv) > 32 * (ct & 1)):
+                used |= 1 << ct
+        gemm(320, Os, E, a_planes=(x_sign, x_nz), B=dn_out, b_rs=Os, b_cs=1, C=GXp, ldc=1, c_cs=320, accumulate=True,
+             tern_tile_mask=used)
         with torch.cuda.stream(side):
             call("svnet_edgeblock_bwd_gather_f32", _p(msg), _p(rev_range), _p(rev_edge), _p(dvc), _p(dzc), P, Cs, Cv, Ov, _p(acat),
                  _p(ds_acc), _p(dv_acc), _p(dbeta_perm), _p(dbeta1), _stream())

@@ -82,6 +82,17 @@ __device__ __forceinline__ float fold16(float a, float b) {
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+// index of the n-th (0-based) set bit among the low 10 bits of mask, or -1
+__device__ __forceinline__ int nth_set_bit10(uint32_t mask, int n) {
+    int res = -1;
+#pragma unroll
+    for (int b = 9; b >= 0; --b) {
+        // count of set bits below b
+        const int below = __popc(mask & ((1u << b) - 1u));
+        if (((mask >> b) & 1u) && below == n) res = b;
+    }
+    return res;
+}
 // value held by lane (l ^ 32)
 __device__ __forceinline__ uint32_t lane_half_swap(uint32_t x) {
     const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
@@ -375,6 +386,19 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
     // v_readlane, so the row gathers of phase C2 never wait on a load of their own index
     const int jv8 = (int)d.idx[min(ew + (lane & 7), E - 1)];
 
+    // The 320 fused columns are 5 words x 64, of which only Cs / Cs / 2Cv / 2Cv / 2Cv are in use: 32-column tiles that lie
+    // entirely in the padding (5 of 10 for the Cs = 32, Cv = 10 layers) are skipped by phase B, and the used ones are dealt
+    // round-robin to the four waves.
+    uint32_t used_tiles = 0;
+#pragma unroll
+    for (int ct = 0; ct < NCOL / 32; ++ct) {
+        const int width = (ct >> 1) < 2 ? Cs : 2 * Cv;
+        if (width > 32 * (ct & 1)) used_tiles |= 1u << ct;
+    }
+    int cts[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) cts[q] = __builtin_amdgcn_readfirstlane(nth_set_bit10(used_tiles, wave + 4 * q));
+
     // sign(W1) fragments of this wave's column tiles for phase B (NKS k-steps x 3 tiles x 4 VGPRs).  Up to Os = 64 they are
     // requested before anything else, so that their L2 latency is hidden behind phase A (at Os = 128 the 96 registers would
     // spill across phase A: loaded at the start of phase B instead)
@@ -386,8 +410,8 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
         const bf16x8* wbt_ = reinterpret_cast<const bf16x8*>(d.w1bt); /* [(col*Os + k) / 8] */                 \
         _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks)                                                     \
             _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                                    \
-                const int ct = wave + 4 * q, kk = ks * 16 + 8 * h_;                                            \
-                if (ks < nks && ct < NCOL / 32 && kk + 8 <= Os) {                                              \
+                const int ct = cts[q], kk = ks * 16 + 8 * h_;                                                  \
+                if (ks < nks && ct >= 0 && kk + 8 <= Os) {                                                     \
                     bfr[ks][q] = wbt_[((int64_t)(ct * 32 + r_) * Os + kk) >> 3];                               \
                 } else {                                                                                       \
                     _Pragma("unroll") for (int j = 0; j < 8; ++j) bfr[ks][q][j] = bf16_from_bits(0);           \
@@ -469,6 +493,23 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
     {
         const int64_t word_row = e0 >> 6;
         const int half = (int)((e0 >> 5) & 1);
+        if (Cs <= 32 && 2 * Cv <= 32) {
+            // narrow layer: every word has at most 32 columns in use, so lanes 0..31 carry the low half of one (plane, word)
+            // entry and lanes 32..63 the low half of the next one: five rounds of 32 ballots instead of ten
+            for (int pi = wave; pi < NW; pi += 4) {
+                const int ent = 2 * pi + (lane >> 5);                  // entry = plane * NW + word
+                const int plane = ent / NW, w = ent - plane * NW;
+                const uint32_t mine = (uint32_t)pl[(plane * TE + (lane & 31)) * NW + w];
+                uint32_t colword = 0u;
+#pragma unroll 8
+                for (int bb = 0; bb < 32; ++bb) {
+                    const uint64_t tb = __ballot((mine >> bb) & 1u);
+                    if ((lane & 31) == bb) colword = lane < 32 ? (uint32_t)tb : (uint32_t)(tb >> 32);
+                }
+                uint32_t* dst = plane == 0 ? d.x_sign32 : d.x_nz32;
+                dst[((word_row * NCOL) + w * 64 + (lane & 31)) * 2 + half] = colword;
+            }
+        } else
         // lanes 0..31 hold the low and lanes 32..63 the high 32 bits of row (lane & 31): one ballot yields two columns
         for (int item = wave; item < 2 * NW; item += 4) {
             const int plane = item / NW, w = item - plane * NW;
@@ -506,7 +547,7 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
                 split3_frag(x, fh, fm, fl);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    if (wave + 4 * q < NCOL / 32) {  // wave-uniform
+                    if (cts[q] >= 0) {  // wave-uniform
                         acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, bfr[ks][q], acc[q], 0, 0, 0);
                         acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fm, bfr[ks][q], acc[q], 0, 0, 0);
                         acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, bfr[ks][q], acc[q], 0, 0, 0);
@@ -517,8 +558,8 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
         __syncthreads();   // every wave has consumed dnl: dxl may now overwrite the same LDS bytes
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            const int ct = wave + 4 * q;
-            if (ct < NCOL / 32) {
+            const int ct = cts[q];
+            if (ct >= 0) {
                 const int col = ct * 32 + r;
                 float csum = 0.f;                       // dL/dbeta of this column: sum over the tile's rows (rows past E are zero)
 #pragma unroll

@@ -12,7 +12,7 @@
 int svnet_mfma_rows(const svnet_gemm_desc& d, hipStream_t st);
 int svnet_mfma_tn(const float* A, int64_t lda, const float* B, int64_t ldb, const uint64_t* b_sign, const uint64_t* b_nz,
                   int64_t M, int64_t P, int64_t Q, float* C, int64_t c_ps, int64_t c_qs, float alpha, int accumulate,
-                  hipStream_t st);
+                  hipStream_t st, uint32_t q_tile_mask = 0);
 
 namespace {
 
@@ -146,7 +146,7 @@ extern "C" int svnet_gemm_f32(const svnet_gemm_desc* desc, void* stream) {
     if (d.a_sign) {
         SVNET_REQUIRE(d.b_cs == 1 && plain_epi, SVNET_E_UNSUPPORTED, "svnet_gemm_f32: ternary A needs row-major B and a plain epilogue");
         return svnet_mfma_tn(d.B, d.b_rs, nullptr, 0, d.a_sign, d.a_nz, d.K, /*P=*/d.N, /*Q=*/d.M, d.C, /*c_ps=*/d.c_cs,
-                             /*c_qs=*/d.ldc, d.alpha, d.accumulate, st);
+                             /*c_qs=*/d.ldc, d.alpha, d.accumulate, st, d.tern_tile_mask);
     }
     // ---- reduction over rows with both operands fp32 rows: A(i,k) = A[k*a_cs + i], B(k,j) = B[k*b_rs + j]
     if (d.a_rs == 1 && d.b_cs == 1 && d.K >= 1024 && plain_epi && d.M <= 1024 && d.N <= 1024) {

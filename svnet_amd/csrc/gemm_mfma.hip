@@ -242,6 +242,7 @@ struct TnArgs {
     int ptiles_per_block;               // p tiles (32 wide) handled by the 4 waves of a workgroup: 1, 2 or 4
     int lds_reduce;                     // combine the row-splitting waves in LDS before the global atomics
     float alpha;
+    uint32_t qmask;                     // ternary B: bit t = q tile t (32 columns) may be non-zero; cleared tiles are skipped
 };
 
 // NQ 32-wide q tiles per workgroup (blockIdx.z picks the group).  The 4 waves cover `ptw` p tiles (1, 2 or 4 per
@@ -417,6 +418,7 @@ __global__ __launch_bounds__(256, 2) void mfma_tn_tern_kernel(TnArgs a) {
 #pragma unroll
                 for (int t = 0; t < NQ; ++t) {
                     if (q0 + t * 32 >= a.Q) break;  // uniform
+                    if (!((a.qmask >> ((q0 >> 5) + t)) & 1u)) continue;   // a tile of padding columns (uniform)
                     const uint32_t nzb = (uint32_t)(wnz[t] >> sh) & 0xFFu;
                     const uint32_t ngb = nzb & ~(uint32_t)(wsg[t] >> sh);
                     const uint4 mg = *reinterpret_cast<const uint4*>(&lut_mag[nzb * 4]);
@@ -454,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void mfma_tn_tern_kernel(TnArgs a) {
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
         const int q = q0 + t * 32 + r;  // D col = lane & 31  <-> B operand column (q)
-        if (q < a.Q) {
+        if (q < a.Q && ((a.qmask >> ((q0 >> 5) + t)) & 1u)) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int pp = p0 + (i & 3) + 8 * (i >> 2) + 4 * h;  // D row <-> A operand row (p)
@@ -552,7 +554,7 @@ int svnet_mfma_rows(const svnet_gemm_desc& d, hipStream_t st) {
 // out(p,q) = alpha * sum_m A[m*lda+p] * B(m,q); B fp32 rows (ldb) or row-sliced ternary planes.
 int svnet_mfma_tn(const float* A, int64_t lda, const float* B, int64_t ldb, const uint64_t* b_sign, const uint64_t* b_nz,
                   int64_t M, int64_t P, int64_t Q, float* C, int64_t c_ps, int64_t c_qs, float alpha, int accumulate,
-                  hipStream_t st) {
+                  hipStream_t st, uint32_t q_tile_mask) {
     if (!accumulate) {
         hipLaunchKernelGGL(zero2d_kernel, dim3(svnet_grid(P * Q, 256)), dim3(256), 0, st, C, P, Q, c_ps, c_qs);
         SVNET_CHECK_LAUNCH("zero2d_kernel");
@@ -561,6 +563,7 @@ int svnet_mfma_tn(const float* A, int64_t lda, const float* B, int64_t ldb, cons
     TnArgs a;
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.b_sign = b_sign; a.b_nz = b_nz;
     a.C = C; a.c_ps = c_ps; a.c_qs = c_qs; a.M = M; a.P = (int)P; a.Q = (int)Q; a.alpha = alpha; a.rows_per_block = 0; a.lds_reduce = 0;
+    a.qmask = q_tile_mask ? q_tile_mask : 0xFFFFFFFFu;
     const bool tern = b_sign != nullptr;
     if (Q <= 32) { if (tern) launch_tn<1, 1>(a, st); else launch_tn<1, 0>(a, st); }
     else if (Q <= 64) { if (tern) launch_tn<2, 1>(a, st); else launch_tn<2, 0>(a, st); }
