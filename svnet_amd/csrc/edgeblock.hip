@@ -16,6 +16,8 @@
 // produced by wave ballots in a lane-friendly bit order; linear1's sign planes are permuted to that order once.
 #include <limits.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -67,8 +69,15 @@ struct FwdArgs {
 };
 
 // OP = scalar outputs per lane (Os <= 64*OP)
-template <int OP>
+__device__ __forceinline__ int tdot(uint32_t xs, uint32_t xz, uint32_t ws, uint32_t wz) {
+    const uint32_t m = xz & wz;
+    return __popc(m) - 2 * __popc(m & (xs ^ ws));
+}
+
+// NARROW: every word has at most 32 columns in use (Cs <= 32 and 2 Cv <= 32): the popcount products run on the low halves only
+template <int OP, bool NARROW>
 __global__ __launch_bounds__(256) void edgeblock_fwd_kernel(FwdArgs fa) {
+    typedef typename std::conditional<NARROW, uint32_t, uint64_t>::type word_t;
     const svnet_edgeblock_desc& d = fa.d;
     const int lane = threadIdx.x & 63;
     // XCD-aware order: workgroups b and b+8 share an XCD, so XCD x walks the clouds x, x+8, ... one after the other and
@@ -87,14 +96,14 @@ __global__ __launch_bounds__(256) void edgeblock_fwd_kernel(FwdArgs fa) {
     const int Cs = d.Cs, Cv = d.Cv, Os = d.Os, Ov = d.Ov, k = (int)d.k;
 
     // my output channels' weight words
-    uint64_t wsg[OP][NW], wnz[OP][NW];
+    word_t wsg[OP][NW], wnz[OP][NW];
 #pragma unroll
     for (int op = 0; op < OP; ++op) {
         const int o = lane + 64 * op;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
-            wsg[op][w] = (o < Os) ? d.w_sign[o * NW + w] : 0ull;
-            wnz[op][w] = (o < Os) ? d.w_nz[o * NW + w] : 0ull;
+            wsg[op][w] = (word_t)((o < Os) ? d.w_sign[o * NW + w] : 0ull);
+            wnz[op][w] = (word_t)((o < Os) ? d.w_nz[o * NW + w] : 0ull);
         }
     }
     const float bd = d.beta_perm[lane], bc = d.beta_perm[64 + lane];
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(256) void edgeblock_fwd_kernel(FwdArgs fa) {
         const uint64_t cst = save ? __ballot(s_lane && fabsf(tc) <= 1.2f) : 0ull;
         int base[OP];
 #pragma unroll
-        for (int op = 0; op < OP; ++op) base[op] = tdot(csg, cnz, wsg[op][1], wnz[op][1]);
+        for (int op = 0; op < OP; ++op) base[op] = tdot((word_t)csg, (word_t)cnz, wsg[op][1], wnz[op][1]);
 
         float vi[3], zi[3][3], ub[3];
 #pragma unroll
@@ -200,9 +209,9 @@ __global__ __launch_bounds__(256) void edgeblock_fwd_kernel(FwdArgs fa) {
             }
 #pragma unroll
             for (int op = 0; op < OP; ++op) {
-                int n = base[op] + tdot(dsg, dnz, wsg[op][0], wnz[op][0]);
+                int n = base[op] + tdot((word_t)dsg, (word_t)dnz, wsg[op][0], wnz[op][0]);
 #pragma unroll
-                for (int jz = 0; jz < 3; ++jz) n += tdot(vsg[jz], vnz[jz], wsg[op][2 + jz], wnz[op][2 + jz]);
+                for (int jz = 0; jz < 3; ++jz) n += tdot((word_t)vsg[jz], (word_t)vnz[jz], wsg[op][2 + jz], wnz[op][2 + jz]);
                 if (n > nmax[op]) { nmax[op] = n; smax[op] = t; }
                 if (n < nmin[op]) { nmin[op] = n; smin[op] = t; }
                 sn[op] += n;
@@ -388,8 +397,14 @@ extern "C" int svnet_edgeblock_fwd_f32(const svnet_edgeblock_desc* desc, void* s
     fa.waves_per_cloud = (int)svnet_cdiv(d.N, fa.points_per_wave);
     const int64_t waves = d.B * fa.waves_per_cloud;
     const unsigned grid = (unsigned)svnet_cdiv(waves, 4);
-    if (d.Os <= 64) hipLaunchKernelGGL((edgeblock_fwd_kernel<1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, fa);
-    else hipLaunchKernelGGL((edgeblock_fwd_kernel<2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, fa);
+    const bool narrow = d.Cs <= 32 && 2 * d.Cv <= 32;
+    if (d.Os <= 64) {
+        if (narrow) hipLaunchKernelGGL((edgeblock_fwd_kernel<1, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, fa);
+        else hipLaunchKernelGGL((edgeblock_fwd_kernel<1, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, fa);
+    } else {
+        if (narrow) hipLaunchKernelGGL((edgeblock_fwd_kernel<2, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, fa);
+        else hipLaunchKernelGGL((edgeblock_fwd_kernel<2, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, fa);
+    }
     SVNET_CHECK_LAUNCH("edgeblock_fwd_kernel");
     return SVNET_OK;
 }
