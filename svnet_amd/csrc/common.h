@@ -49,4 +49,8 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+// Single-instruction square root / reciprocal (v_sqrt_f32, v_rcp_f32: 1 ulp each) for the per-edge vector norms of the fused
+// kernels, where the correctly rounded sequences (10 instructions each) were a fifth of the instruction stream.
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 #endif

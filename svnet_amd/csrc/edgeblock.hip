@@ -220,8 +220,8 @@ __global__ __launch_bounds__(256) void edgeblock_fwd_kernel(FwdArgs fa) {
             }
             if (o_lane) {
                 const float vp0 = u0 + ub[0], vp1 = u1 + ub[1], vp2 = u2 + ub[2];
-                const float nn = sqrtf(vp0 * vp0 + vp1 * vp1 + vp2 * vp2) + VEPS;
-                const float inv = 1.f / nn;
+                const float nn = fast_sqrt(vp0 * vp0 + vp1 * vp1 + vp2 * vp2) + VEPS;
+                const float inv = fast_rcp(nn);
                 av[0] += vp0; av[1] += vp1; av[2] += vp2;
                 avn[0] += vp0 * inv; avn[1] += vp1 * inv; avn[2] += vp2 * inv;
                 sv1 += (double)nn;

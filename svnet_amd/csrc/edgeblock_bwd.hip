@@ -262,12 +262,13 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_vec_kernel(VecArgs va) {
             const float u0 = n_u0, u1 = n_u1, u2 = n_u2;
             if (t0 + G < k) SVNET_LOAD_U(t0 + G);
             const float vp0 = u0 + ub0, vp1 = u1 + ub1, vp2 = u2 + ub2;
-            const float nv = sqrtf(vp0 * vp0 + vp1 * vp1 + vp2 * vp2);
+            const float nv = fast_sqrt(vp0 * vp0 + vp1 * vp1 + vp2 * vp2);
             const float nn = nv + VEPS;
-            const float q = avc + bvc / nn;
+            const float rn = fast_rcp(nn);
+            const float q = avc + bvc * rn;
             const float gdot = ge0 * vp0 + ge1 * vp1 + ge2 * vp2;
-            const float dnn = -gdot * bvc / (nn * nn) + c0 + c1 * nn;
-            const float kk = nv > 0.f ? dnn / nv : 0.f;
+            const float dnn = -gdot * bvc * rn * rn + c0 + c1 * nn;
+            const float kk = nv > 0.f ? dnn * fast_rcp(nv) : 0.f;
             const float d0 = ge0 * q + kk * vp0, d1 = ge1 * q + kk * vp1, d2 = ge2 * q + kk * vp2;
             if (ok) {   // the neighbour's share goes into the edge's message row (summed over the reverse lists later)
                 float* m = d.msg + (gp * k + t0 + g) * R + (d.Cs + 3 * d.Cv + 9);

@@ -120,8 +120,8 @@ __global__ __launch_bounds__(256) void xyzblock_fwd_kernel(XyzFwdArgs fa) {
             float vp[3];
 #pragma unroll
             for (int dd = 0; dd < 3; ++dd) vp[dd] = w2a * e.ve[dd][0] + w2b * e.ve[dd][1];
-            const float nn = sqrtf(vp[0] * vp[0] + vp[1] * vp[1] + vp[2] * vp[2]) + VEPS;
-            const float inv = 1.f / nn;
+            const float nn = fast_sqrt(vp[0] * vp[0] + vp[1] * vp[1] + vp[2] * vp[2]) + VEPS;
+            const float inv = fast_rcp(nn);
 #pragma unroll
             for (int dd = 0; dd < 3; ++dd) { av[dd] += vp[dd]; avn[dd] += vp[dd] * inv; }
             sv1 += (double)nn;
@@ -323,12 +323,13 @@ __global__ __launch_bounds__(256) void xyzblock_bwd_kernel(svnet_xyzblock_bwd_de
             float vp[3];
 #pragma unroll
             for (int dd = 0; dd < 3; ++dd) vp[dd] = w2a * e.ve[dd][0] + w2b * e.ve[dd][1];
-            const float nv = sqrtf(vp[0] * vp[0] + vp[1] * vp[1] + vp[2] * vp[2]);
+            const float nv = fast_sqrt(vp[0] * vp[0] + vp[1] * vp[1] + vp[2] * vp[2]);
             const float nn = nv + VEPS;
-            const float q = avc + bvc / nn;
+            const float rn = fast_rcp(nn);
+            const float q = avc + bvc * rn;
             const float gdot = gv0 * vp[0] + gv1 * vp[1] + gv2 * vp[2];
-            const float dnn = -gdot * bvc / (nn * nn) + c0 + c1 * nn;
-            const float kk = nv > 0.f ? dnn / nv : 0.f;
+            const float dnn = -gdot * bvc * rn * rn + c0 + c1 * nn;
+            const float kk = nv > 0.f ? dnn * fast_rcp(nv) : 0.f;
             const float gvv[3] = {gv0, gv1, gv2};
 #pragma unroll
             for (int dd = 0; dd < 3; ++dd) {
