@@ -75,8 +75,15 @@ __device__ __forceinline__ int tdot(uint32_t xs, uint32_t xz, uint32_t ws, uint3
 }
 
 // NARROW: every word has at most 32 columns in use (Cs <= 32 and 2 Cv <= 32): the popcount products run on the low halves only
+// The kernel proper.  Every table comes in as a __restrict__ parameter (the kernel below just unpacks the descriptor): with
+// the aliasing question settled, the wave-uniform reads (the zz rows) become scalar loads instead of vector loads + readlanes.
 template <int OP, bool NARROW>
-__global__ __launch_bounds__(256) void edgeblock_fwd_kernel(FwdArgs fa) {
+__device__ __forceinline__ void edgeblock_fwd_body(const FwdArgs& fa, const float* __restrict__ ts, const float* __restrict__ tv,
+                                                   const int64_t* __restrict__ tidx, const float* __restrict__ tzz,
+                                                   const float* __restrict__ tut, int16_t* __restrict__ o_n16,
+                                                   uint64_t* __restrict__ o_planes, int32_t* __restrict__ o_nmax,
+                                                   int32_t* __restrict__ o_nmin, uint8_t* __restrict__ o_smax,
+                                                   uint8_t* __restrict__ o_smin, float* __restrict__ o_mv, float* __restrict__ o_mvn) {
     typedef typename std::conditional<NARROW, uint32_t, uint64_t>::type word_t;
     const svnet_edgeblock_desc& d = fa.d;
     const int lane = threadIdx.x & 63;
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(256) void edgeblock_fwd_kernel(FwdArgs fa) {
     const int cm = diff_lane ? lane : lane - Cv;
     const bool o_lane = lane < Ov;
 
-    const bool save = d.planes != nullptr;   // training: keep n and the ternary / STE planes of every edge for the backward
+    const bool save = o_planes != nullptr;   // training: keep n and the ternary / STE planes of every edge for the backward
 
     long long sn[OP], sn2[OP];
 #pragma unroll
@@ -128,12 +135,12 @@ __global__ __launch_bounds__(256) void edgeblock_fwd_kernel(FwdArgs fa) {
     // Neighbour ids: lane t of one coalesced load holds idx[p][t] (k <= 64) and v_readlane hands it to the scalar unit, so the
     // gathers of an edge never wait on a load of their own index; the next point's ids are requested a whole point ahead.
     const int lk = min(lane, k - 1);
-    int jv_next = (p_begin < p_end) ? (int)d.idx[(b * d.N + p_begin) * k + lk] : 0;
+    int jv_next = (p_begin < p_end) ? (int)tidx[(b * d.N + p_begin) * k + lk] : 0;
     for (int p = p_begin; p < p_end; ++p) {
         const int64_t gp = b * d.N + p;
         const int jv = jv_next;
-        if (p + 1 < p_end) jv_next = (int)d.idx[(gp + 1) * k + lk];
-        const float s_i = s_lane ? d.s[gp * Cs + min(lane, Cs - 1)] : 0.f;
+        if (p + 1 < p_end) jv_next = (int)tidx[(gp + 1) * k + lk];
+        const float s_i = s_lane ? ts[gp * Cs + min(lane, Cs - 1)] : 0.f;
         gs_cen += s_i;
         const float tc = s_i + bc;
         const uint64_t csg = __ballot(s_lane && tc > 0.f), cnz = __ballot(s_lane && tc != 0.f);
@@ -145,106 +152,113 @@ __global__ __launch_bounds__(256) void edgeblock_fwd_kernel(FwdArgs fa) {
         float vi[3], zi[3][3], ub[3];
 #pragma unroll
         for (int dd = 0; dd < 3; ++dd) {
-            vi[dd] = v2_lane ? d.v[(gp * 3 + dd) * Cv + cm] : 0.f;
-            const float* zrow = d.zz + (gp * 3 + dd) * 6;
+            vi[dd] = v2_lane ? tv[(gp * 3 + dd) * Cv + cm] : 0.f;
+            const float* zrow = tzz + (gp * 3 + dd) * 6;
 #pragma unroll
             for (int jz = 0; jz < 3; ++jz) zi[dd][jz] = zrow[3 + jz] - zrow[jz];  // Zq_i - Zp_i
-            ub[dd] = o_lane ? d.ut[(gp * 3 + dd) * 2 * Ov + Ov + lane] - d.ut[(gp * 3 + dd) * 2 * Ov + lane] : 0.f;  // T_i - U_i
+            ub[dd] = o_lane ? tut[(gp * 3 + dd) * 2 * Ov + Ov + lane] - tut[(gp * 3 + dd) * 2 * Ov + lane] : 0.f;  // T_i - U_i
         }
         int nmax[OP], nmin[OP], smax[OP], smin[OP];
 #pragma unroll
         for (int op = 0; op < OP; ++op) { nmax[op] = INT_MIN; nmin[op] = INT_MAX; smax[op] = 0; smin[op] = 0; }
         float av[3] = {0.f, 0.f, 0.f}, avn[3] = {0.f, 0.f, 0.f};
 
-        // neighbour rows are loaded one edge ahead (all lanes, clamped channel index: no exec-masked branches)
+        // neighbour rows are loaded one edge ahead (all lanes, clamped channel index: no exec-masked branches) into two
+        // alternating register sets (the loop is unrolled by two, so no set is ever copied).  The zz row is wave-uniform; its
+        // address carries an opaque zero so that it stays a plain (broadcast) vector load instead of load + 18 readlanes.
         const int ls = min(lane, Cs - 1), ld = min(lane, Cv - 1), lo = min(lane, Ov - 1);
-        float n_sj, n_vj0, n_vj1, n_vj2, n_u0, n_u1, n_u2, n_z[9];
-#define SVNET_LOAD_NBR(T)                                                                   \
+        const int opaque0 = (int)__builtin_amdgcn_mbcnt_lo(0u, 0u);
+        struct Nbr { float sj, vj0, vj1, vj2, u0, u1, u2, z[9]; };
+        Nbr na, nb;
+#define SVNET_LOAD_NBR(N_, T)                                                               \
     do {                                                                                    \
         const int64_t gj_ = b * d.N + __builtin_amdgcn_readlane(jv, (T));                   \
-        n_sj = d.s[gj_ * Cs + ls];                                                          \
-        n_vj0 = d.v[(gj_ * 3 + 0) * Cv + ld]; n_vj1 = d.v[(gj_ * 3 + 1) * Cv + ld]; n_vj2 = d.v[(gj_ * 3 + 2) * Cv + ld]; \
-        n_u0 = d.ut[(gj_ * 3 + 0) * 2 * Ov + lo]; n_u1 = d.ut[(gj_ * 3 + 1) * 2 * Ov + lo]; n_u2 = d.ut[(gj_ * 3 + 2) * 2 * Ov + lo]; \
-        const float* zr_ = d.zz + gj_ * 18;                                                 \
-        n_z[0] = zr_[0]; n_z[1] = zr_[1]; n_z[2] = zr_[2]; n_z[3] = zr_[6]; n_z[4] = zr_[7]; n_z[5] = zr_[8];              \
-        n_z[6] = zr_[12]; n_z[7] = zr_[13]; n_z[8] = zr_[14];                               \
+        N_.sj = ts[gj_ * Cs + ls];                                                          \
+        N_.vj0 = tv[(gj_ * 3 + 0) * Cv + ld]; N_.vj1 = tv[(gj_ * 3 + 1) * Cv + ld]; N_.vj2 = tv[(gj_ * 3 + 2) * Cv + ld]; \
+        N_.u0 = tut[(gj_ * 3 + 0) * 2 * Ov + lo]; N_.u1 = tut[(gj_ * 3 + 1) * 2 * Ov + lo]; N_.u2 = tut[(gj_ * 3 + 2) * 2 * Ov + lo]; \
+        const float* zr_ = tzz + gj_ * 18 + opaque0;                                        \
+        N_.z[0] = zr_[0]; N_.z[1] = zr_[1]; N_.z[2] = zr_[2]; N_.z[3] = zr_[6]; N_.z[4] = zr_[7]; N_.z[5] = zr_[8];        \
+        N_.z[6] = zr_[12]; N_.z[7] = zr_[13]; N_.z[8] = zr_[14];                            \
     } while (0)
-        SVNET_LOAD_NBR(0);
-        for (int t = 0; t < k; ++t) {
-            const float sj = n_sj, vj0 = n_vj0, vj1 = n_vj1, vj2 = n_vj2, u0 = n_u0, u1 = n_u1, u2 = n_u2;
-            float zj[9];
-#pragma unroll
-            for (int q = 0; q < 9; ++q) zj[q] = n_z[q];
-            if (t + 1 < k) SVNET_LOAD_NBR(t + 1);
-            const float sd = s_lane ? (sj - s_i) : 0.f;
-            gs_diff += sd;
-            const float td = sd + bd;
-            const uint64_t dsg = __ballot(s_lane && td > 0.f), dnz = __ballot(s_lane && td != 0.f);
-            float ve[3], z[3][3];
-            ve[0] = diff_lane ? (vj0 - vi[0]) : vi[0];
-            ve[1] = diff_lane ? (vj1 - vi[1]) : vi[1];
-            ve[2] = diff_lane ? (vj2 - vi[2]) : vi[2];
-#pragma unroll
-            for (int dd = 0; dd < 3; ++dd)
-#pragma unroll
-                for (int jz = 0; jz < 3; ++jz) z[dd][jz] = zj[dd * 3 + jz] + zi[dd][jz];
-            uint64_t vsg[3], vnz[3], vst[3];
-#pragma unroll
-            for (int jz = 0; jz < 3; ++jz) {
-                const float tv = ve[0] * z[0][jz] + ve[1] * z[1][jz] + ve[2] * z[2][jz] + bv[jz];
-                vsg[jz] = __ballot(v2_lane && tv > 0.f);
-                vnz[jz] = __ballot(v2_lane && tv != 0.f);
-                vst[jz] = save ? __ballot(v2_lane && fabsf(tv) <= 1.2f) : 0ull;
-            }
-            const int64_t e = gp * k + t;
-            if (save) {  // wave-uniform.  planes[e][plane][word]: lane 5*plane + word holds one 64-bit word of the edge row
-                const uint64_t dst = __ballot(s_lane && fabsf(td) <= 1.2f);
-                uint64_t val = dsg;
-                val = lane == 1 ? csg : val;  val = lane == 2 ? vsg[0] : val;  val = lane == 3 ? vsg[1] : val;  val = lane == 4 ? vsg[2] : val;
-                val = lane == 5 ? dnz : val;  val = lane == 6 ? cnz : val;     val = lane == 7 ? vnz[0] : val;  val = lane == 8 ? vnz[1] : val;
-                val = lane == 9 ? vnz[2] : val;
-                val = lane == 10 ? dst : val; val = lane == 11 ? cst : val;    val = lane == 12 ? vst[0] : val; val = lane == 13 ? vst[1] : val;
-                val = lane == 14 ? vst[2] : val;
-                if (lane < 3 * NW) d.planes[e * (3 * NW) + lane] = val;
-            }
-#pragma unroll
-            for (int op = 0; op < OP; ++op) {
-                int n = base[op] + tdot((word_t)dsg, (word_t)dnz, wsg[op][0], wnz[op][0]);
-#pragma unroll
-                for (int jz = 0; jz < 3; ++jz) n += tdot((word_t)vsg[jz], (word_t)vnz[jz], wsg[op][2 + jz], wnz[op][2 + jz]);
-                if (n > nmax[op]) { nmax[op] = n; smax[op] = t; }
-                if (n < nmin[op]) { nmin[op] = n; smin[op] = t; }
-                sn[op] += n;
-                sn2[op] += n * n;
-                if (save && lane + 64 * op < Os) d.n16[e * Os + lane + 64 * op] = (int16_t)n;   // |n| <= 320
-            }
-            if (o_lane) {
-                const float vp0 = u0 + ub[0], vp1 = u1 + ub[1], vp2 = u2 + ub[2];
-                const float nn = fast_sqrt(vp0 * vp0 + vp1 * vp1 + vp2 * vp2) + VEPS;
-                const float inv = fast_rcp(nn);
-                av[0] += vp0; av[1] += vp1; av[2] += vp2;
-                avn[0] += vp0 * inv; avn[1] += vp1 * inv; avn[2] += vp2 * inv;
-                sv1 += (double)nn;
-                sv2 += (double)nn * (double)nn;
-            }
+#define SVNET_WL(W, L)                                                                                           \
+    do {                                                                                                             \
+        asm("v_writelane_b32 %0, %1, " #L : "+v"(vlo) : "s"((int)(uint32_t)(W)));                                    \
+        if (!NARROW) asm("v_writelane_b32 %0, %1, " #L : "+v"(vhi) : "s"((int)(uint32_t)((W) >> 32)));               \
+    } while (0)
+#define SVNET_EDGE(CUR, NXT, T)                                                                                              \
+    do {                                                                                                                     \
+        const int t = (T);                                                                                                   \
+        if (t + 1 < k) SVNET_LOAD_NBR(NXT, t + 1);                                                                           \
+        const float sd = s_lane ? (CUR.sj - s_i) : 0.f;                                                                      \
+        gs_diff += sd;                                                                                                       \
+        const float td = sd + bd;                                                                                            \
+        const uint64_t dsg = __ballot(s_lane && td > 0.f), dnz = __ballot(s_lane && td != 0.f);                              \
+        float ve[3], z[3][3];                                                                                                \
+        ve[0] = diff_lane ? (CUR.vj0 - vi[0]) : vi[0];                                                                       \
+        ve[1] = diff_lane ? (CUR.vj1 - vi[1]) : vi[1];                                                                       \
+        ve[2] = diff_lane ? (CUR.vj2 - vi[2]) : vi[2];                                                                       \
+        _Pragma("unroll") for (int dd = 0; dd < 3; ++dd)                                                                     \
+            _Pragma("unroll") for (int jz = 0; jz < 3; ++jz) z[dd][jz] = CUR.z[dd * 3 + jz] + zi[dd][jz];                    \
+        uint64_t vsg[3], vnz[3], vst[3];                                                                                     \
+        _Pragma("unroll") for (int jz = 0; jz < 3; ++jz) {                                                                   \
+            const float tvv = ve[0] * z[0][jz] + ve[1] * z[1][jz] + ve[2] * z[2][jz] + bv[jz];                               \
+            vsg[jz] = __ballot(v2_lane && tvv > 0.f);                                                                        \
+            vnz[jz] = __ballot(v2_lane && tvv != 0.f);                                                                       \
+            vst[jz] = save ? __ballot(v2_lane && fabsf(tvv) <= 1.2f) : 0ull;                                                 \
+        }                                                                                                                    \
+        const int64_t e = gp * k + t;                                                                                        \
+        if (save) { /* wave-uniform.  planes[e][plane][word]: lane 5*plane + word holds one 64-bit word of the edge row */  \
+            const uint64_t dst = __ballot(s_lane && fabsf(td) <= 1.2f);                                                      \
+            /* v_writelane drops each (wave-uniform) ballot word straight into its lane: no lane masks, no selects */       \
+            int vlo = 0, vhi = 0;                                                                                            \
+            SVNET_WL(dsg, 0);  SVNET_WL(csg, 1);  SVNET_WL(vsg[0], 2);  SVNET_WL(vsg[1], 3);  SVNET_WL(vsg[2], 4);           \
+            SVNET_WL(dnz, 5);  SVNET_WL(cnz, 6);  SVNET_WL(vnz[0], 7);  SVNET_WL(vnz[1], 8);  SVNET_WL(vnz[2], 9);           \
+            SVNET_WL(dst, 10); SVNET_WL(cst, 11); SVNET_WL(vst[0], 12); SVNET_WL(vst[1], 13); SVNET_WL(vst[2], 14);          \
+            if (lane < 3 * NW) o_planes[e * (3 * NW) + lane] = ((uint64_t)(uint32_t)vhi << 32) | (uint32_t)vlo;             \
+        }                                                                                                                    \
+        _Pragma("unroll") for (int op = 0; op < OP; ++op) {                                                                  \
+            int n = base[op] + tdot((word_t)dsg, (word_t)dnz, wsg[op][0], wnz[op][0]);                                       \
+            _Pragma("unroll") for (int jz = 0; jz < 3; ++jz) n += tdot((word_t)vsg[jz], (word_t)vnz[jz], wsg[op][2 + jz], wnz[op][2 + jz]); \
+            if (n > nmax[op]) { nmax[op] = n; smax[op] = t; }                                                                \
+            if (n < nmin[op]) { nmin[op] = n; smin[op] = t; }                                                                \
+            sn[op] += n;                                                                                                     \
+            sn2[op] += n * n;                                                                                                \
+            if (save && lane + 64 * op < Os) o_n16[e * Os + lane + 64 * op] = (int16_t)n;   /* |n| <= 320 */                 \
+        }                                                                                                                    \
+        if (o_lane) {                                                                                                        \
+            const float vp0 = CUR.u0 + ub[0], vp1 = CUR.u1 + ub[1], vp2 = CUR.u2 + ub[2];                                    \
+            const float nn = fast_sqrt(vp0 * vp0 + vp1 * vp1 + vp2 * vp2) + VEPS;                                            \
+            const float inv = fast_rcp(nn);                                                                                  \
+            av[0] += vp0; av[1] += vp1; av[2] += vp2;                                                                        \
+            avn[0] += vp0 * inv; avn[1] += vp1 * inv; avn[2] += vp2 * inv;                                                   \
+            sv1 += (double)nn;                                                                                               \
+            sv2 += (double)nn * (double)nn;                                                                                  \
+        }                                                                                                                    \
+    } while (0)
+        SVNET_LOAD_NBR(na, 0);
+        for (int t2 = 0; t2 < k; t2 += 2) {
+            SVNET_EDGE(na, nb, t2);
+            if (t2 + 1 < k) SVNET_EDGE(nb, na, t2 + 1);
         }
+#undef SVNET_EDGE
+#undef SVNET_WL
 #undef SVNET_LOAD_NBR
         const float invk = 1.f / (float)k;
 #pragma unroll
         for (int op = 0; op < OP; ++op) {
             const int o = lane + 64 * op;
             if (o < Os) {
-                d.n_max[gp * Os + o] = nmax[op];
-                d.n_min[gp * Os + o] = nmin[op];
-                d.slot_max[gp * Os + o] = (uint8_t)smax[op];
-                d.slot_min[gp * Os + o] = (uint8_t)smin[op];
+                o_nmax[gp * Os + o] = nmax[op];
+                o_nmin[gp * Os + o] = nmin[op];
+                o_smax[gp * Os + o] = (uint8_t)smax[op];
+                o_smin[gp * Os + o] = (uint8_t)smin[op];
             }
         }
         if (o_lane) {
 #pragma unroll
             for (int dd = 0; dd < 3; ++dd) {
-                d.mv[(gp * 3 + dd) * Ov + lane] = av[dd] * invk;
-                d.mvn[(gp * 3 + dd) * Ov + lane] = avn[dd] * invk;
+                o_mv[(gp * 3 + dd) * Ov + lane] = av[dd] * invk;
+                o_mvn[(gp * 3 + dd) * Ov + lane] = avn[dd] * invk;
             }
         }
     }
@@ -280,6 +294,13 @@ __global__ __launch_bounds__(256) void edgeblock_fwd_kernel(FwdArgs fa) {
         atomicAdd(&d.gate_sum[b * 2 * Cs + lane], gs_diff);
         atomicAdd(&d.gate_sum[b * 2 * Cs + Cs + lane], gs_cen * (float)k);
     }
+}
+
+// register budget: 4 waves per SIMD (<= 128 VGPRs) up to Os = 64, 3 (<= 168) above: the kernel sat 1 and 3 registers over
+template <int OP, bool NARROW>
+__global__ __launch_bounds__(256, (OP == 1 ? 4 : 3)) void edgeblock_fwd_kernel(FwdArgs fa) {
+    const svnet_edgeblock_desc& d = fa.d;
+    edgeblock_fwd_body<OP, NARROW>(fa, d.s, d.v, d.idx, d.zz, d.ut, d.n16, d.planes, d.n_max, d.n_min, d.slot_max, d.slot_min, d.mv, d.mvn);
 }
 
 // Per-channel affine forms from the batch (or running) statistics.
