@@ -44,7 +44,9 @@ constexpr float VEPS = 1e-6f;
 constexpr int NW = 5;
 constexpr int NCOL = NW * 64;      // 320 feature columns in fused bit order
 constexpr int TE = 32;             // edges per tile
-constexpr int DXS = NCOL + 4;      // LDS row stride of the dx tile (floats)
+// LDS row stride (floats) of the dx tile.  Only the columns in use are kept, compacted as [d (Cs) | c (Cs) | v0 | v1 | v2 (2Cv each)];
+// the stride is odd, so row-wise and column-wise walks are both free of bank conflicts.
+__host__ __device__ __forceinline__ int dx_stride(int Cs, int Cv) { return (2 * Cs + 6 * Cv) | 1; }
 
 __device__ __forceinline__ int tdot(uint64_t xs, uint64_t xz, uint64_t ws, uint64_t wz) {
     const uint64_t m = xz & wz;
@@ -361,10 +363,12 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Cs = d.Cs, Cv = d.Cv, Os = d.Os;
     const int DNS = Os + 4;
+    const int DXS = dx_stride(Cs, Cv);
+    const int dx_floats = max(TE * DXS, TE * DNS);                  // dnl (phase A -> B) shares the bytes of dxl
     float* dxl = reinterpret_cast<float*>(smem);                    // [TE][DXS]   masked dx_b            (phases B -> C)
     float* dnl = dxl;                                                // [TE][DNS]   dL/dn = dy_pre*scale   (phases A -> B), ALIASES dxl:
                                                                      //             phase B pulls it into registers before writing dxl
-    uint64_t* pl = reinterpret_cast<uint64_t*>(dxl + TE * DXS);      // [3][TE][NW] sign | nz | ste (row-major words)
+    uint64_t* pl = reinterpret_cast<uint64_t*>(dxl + ((dx_floats + 3) & ~3));   // [3][TE][NW] sign | nz | ste (row-major words)
 
     PHASE_INIT();
     const int tid = threadIdx.x, lane = tid & 63;
@@ -562,17 +566,20 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
             const int ct = cts[q];
             if (ct >= 0) {
                 const int col = ct * 32 + r;
+                const int wd = ct >> 1, wi = (ct & 1) * 32 + r;                       // word, index inside the word
+                const bool in_use = wi < (wd < 2 ? Cs : 2 * Cv);
+                const int ccol = (wd < 2 ? wd * Cs : 2 * Cs + (wd - 2) * 2 * Cv) + wi;   // compact LDS column
                 float csum = 0.f;                       // dL/dbeta of this column: sum over the tile's rows (rows past E are zero)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
                     const uint64_t st = pl[(2 * TE + row) * NW + (col >> 6)];
                     const float v = ((st >> (col & 63)) & 1ull) ? acc[q][i] : 0.f;
-                    dxl[row * DXS + col] = v;
+                    if (in_use) dxl[row * DXS + ccol] = v;
                     csum += v;
                 }
                 const float other = __uint_as_float(lane_half_swap(__float_as_uint(csum)));
-                if (h == 0) { const float t = csum + other; if (t != 0.f) ATOMIC_ADD(&d.dbeta_perm[col], t); }
+                if (h == 0 && in_use) { const float t = csum + other; if (t != 0.f) ATOMIC_ADD(&d.dbeta_perm[col], t); }
             }
         }
     }
@@ -618,7 +625,7 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
                     }
                     const float d0 = dxl[r * DXS + c] + g0c;
                     d.msg[(e0 + r) * R + c] = d0;
-                    const float cen = (dxl[r * DXS + 64 + c] + g1c) - d0;
+                    const float cen = (dxl[r * DXS + Cs + c] + g1c) - d0;
                     if (use_lds) atomicAdd(&csl[slot * Cs + c], cen);
                     else ATOMIC_ADD(&d.ds_acc[(gp_first + slot) * Cs + c], cen);
                 }
@@ -681,7 +688,8 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
                 czq = czq8 = 0.f;
             }
             const float* row = dxl + r * DXS;
-            const float g0 = v2_lane ? row[128 + lane] : 0.f, g1 = v2_lane ? row[192 + lane] : 0.f, g2 = v2_lane ? row[256 + lane] : 0.f;
+            const float g0 = v2_lane ? row[2 * Cs + lane] : 0.f, g1 = v2_lane ? row[2 * Cs + 2 * Cv + lane] : 0.f,
+                        g2 = v2_lane ? row[2 * Cs + 4 * Cv + lane] : 0.f;
             // v2s backward: s_v[c2][jz] = sum_d ve[d][c2] * z[d][jz]
             const float ve0 = diff_lane ? (in.vj0 - in.vi0) : (v2_lane ? in.vi0 : 0.f);
             const float ve1 = diff_lane ? (in.vj1 - in.vi1) : (v2_lane ? in.vi1 : 0.f);
@@ -784,7 +792,9 @@ extern "C" int svnet_edgeblock_bwd_f32(const svnet_edgeblock_bwd_desc* desc, voi
     if (!do_tile) return SVNET_OK;
 
     // scalar path: 32-edge tiles
-    const size_t lds = (size_t)TE * DXS * 4 + (size_t)3 * TE * NW * 8;   // dnl aliases dxl
+    const int dxs = dx_stride(d.Cs, d.Cv), dns = d.Os + 4;
+    const int dx_floats = TE * (dxs > dns ? dxs : dns);                 // dnl aliases dxl
+    const size_t lds = (size_t)((dx_floats + 3) & ~3) * 4 + (size_t)3 * TE * NW * 8;
     const unsigned grid = (unsigned)svnet_cdiv(E, TE);
 #define SVNET_LAUNCH_BWD(MODE)                                                                                              \
     do {                                                                                                                    \

@@ -365,7 +365,7 @@ extern "C" int svnet_knn_f32(const float* x, int64_t B, int64_t N, int64_t C, in
     else if (N <= 128) launch_main<2, 8>(xT, xx, B, n, c, k, idx_out, st);
     else if (N <= 256) launch_main<4, 8>(xT, xx, B, n, c, k, idx_out, st);
     else if (N <= 512) launch_main<8, 8>(xT, xx, B, n, c, k, idx_out, st);
-    else if (N <= 1024) launch_main<16, 8>(xT, xx, B, n, c, k, idx_out, st);
+    else if (N <= 1024) launch_main<16, 4>(xT, xx, B, n, c, k, idx_out, st);   // 4 queries per wave: <= 128 VGPRs, 4 waves per SIMD
     else if (N <= 2048) launch_main<32, 4>(xT, xx, B, n, c, k, idx_out, st);
     else launch_main<64, 2>(xT, xx, B, n, c, k, idx_out, st);
     SVNET_CHECK_LAUNCH("knn_main_kernel");
