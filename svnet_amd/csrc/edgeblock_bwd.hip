@@ -359,7 +359,7 @@ __device__ __forceinline__ void load_edge(const svnet_edgeblock_bwd_desc& d, con
 
 // MODE: 0 = product; 1..3 = timing-only ablations (SVNET_BWD_MODE), wrong results.  NKS = k-steps of phase B (Os <= 16*NKS)
 template <int MODE, int NKS>
-__global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_desc d) {
+__global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_desc d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Cs = d.Cs, Cv = d.Cv, Os = d.Os;
     const int DNS = Os + 4;
@@ -408,23 +408,24 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
     // requested before anything else, so that their L2 latency is hidden behind phase A (at Os = 128 the 96 registers would
     // spill across phase A: loaded at the start of phase B instead)
     const int nks = (Os + 15) >> 4;
-    bf16x8 bfr[NKS][3];
-#define SVNET_LOAD_BFR()                                                                                       \
+    constexpr int NKB = NKS < 4 ? NKS : 4;          // k-steps whose fragments are in registers at a time
+    bf16x8 bfr[NKB][3];
+#define SVNET_LOAD_BFR(KS0)                                                                                    \
     do {                                                                                                       \
         const int r_ = lane & 31, h_ = lane >> 5;                                                              \
         const bf16x8* wbt_ = reinterpret_cast<const bf16x8*>(d.w1bt); /* [(col*Os + k) / 8] */                 \
-        _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks)                                                     \
+        _Pragma("unroll") for (int kb = 0; kb < NKB; ++kb)                                                     \
             _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                                    \
-                const int ct = cts[q], kk = ks * 16 + 8 * h_;                                                  \
-                if (ks < nks && ct >= 0 && kk + 8 <= Os) {                                                     \
-                    bfr[ks][q] = wbt_[((int64_t)(ct * 32 + r_) * Os + kk) >> 3];                               \
+                const int ct = cts[q], ks_ = (KS0) + kb, kk = ks_ * 16 + 8 * h_;                               \
+                if (ks_ < nks && ct >= 0 && kk + 8 <= Os) {                                                    \
+                    bfr[kb][q] = wbt_[((int64_t)(ct * 32 + r_) * Os + kk) >> 3];                               \
                 } else {                                                                                       \
-                    _Pragma("unroll") for (int j = 0; j < 8; ++j) bfr[ks][q][j] = bf16_from_bits(0);           \
+                    _Pragma("unroll") for (int j = 0; j < 8; ++j) bfr[kb][q][j] = bf16_from_bits(0);           \
                 }                                                                                              \
             }                                                                                                  \
     } while (0)
     constexpr bool HOIST_B = NKS <= 4;
-    if (HOIST_B) SVNET_LOAD_BFR();
+    if (HOIST_B) SVNET_LOAD_BFR(0);
 
     // ================= phase A: dL/dy_pre of the tile's 32 x Os edge-channels from the saved integer sums =========
     //   dy_pre = cs*(g - m1 - xhat*m2), xhat = (scale*n - mean)*invstd, g = gy[p,o] on the pooled edge, else 0
@@ -535,27 +536,31 @@ __global__ __launch_bounds__(256, 3) void edgeblock_bwd_kernel(svnet_edgeblock_b
     // ================= phase B: dx_b = dnl . sign(W1), masked by the STE plane =================
     {
         const int r = lane & 31, h = lane >> 5;
-        if (!HOIST_B) SVNET_LOAD_BFR();
         f32x16 acc[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            if (ks < nks) {
-                const int kk = ks * 16 + 8 * h;
-                const float4 x0 = *reinterpret_cast<const float4*>(&dnl[r * DNS + kk]);      // DNS % 4 == 0, kk % 8 == 0
-                const float4 x1 = *reinterpret_cast<const float4*>(&dnl[r * DNS + kk + 4]);  // Os % 8 == 0: no ragged k
-                const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-                bf16x8 fh, fm, fl;
-                split3_frag(x, fh, fm, fl);
+        for (int ks0 = 0; ks0 < NKS; ks0 += NKB) {
+            if (!HOIST_B) SVNET_LOAD_BFR(ks0);       // Os = 128: two groups of four k-steps (96 fragment registers would cost a wave per SIMD)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    if (cts[q] >= 0) {  // wave-uniform
-                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, bfr[ks][q], acc[q], 0, 0, 0);
-                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fm, bfr[ks][q], acc[q], 0, 0, 0);
-                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, bfr[ks][q], acc[q], 0, 0, 0);
+            for (int kb = 0; kb < NKB; ++kb) {
+                const int ks = ks0 + kb;
+                if (ks < nks) {
+                    const int kk = ks * 16 + 8 * h;
+                    const float4 x0 = *reinterpret_cast<const float4*>(&dnl[r * DNS + kk]);      // DNS % 4 == 0, kk % 8 == 0
+                    const float4 x1 = *reinterpret_cast<const float4*>(&dnl[r * DNS + kk + 4]);  // Os % 8 == 0: no ragged k
+                    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                    bf16x8 fh, fm, fl;
+                    split3_frag(x, fh, fm, fl);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        if (cts[q] >= 0) {  // wave-uniform
+                            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, bfr[kb][q], acc[q], 0, 0, 0);
+                            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fm, bfr[kb][q], acc[q], 0, 0, 0);
+                            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, bfr[kb][q], acc[q], 0, 0, 0);
+                        }
                     }
                 }
             }
