@@ -643,6 +643,15 @@ class EdgeBlock(torch.autograd.Function):
             dev, ((2 * Os,), F), ((2 * Ov,), F), ((B, Ov), F), ((H, 2 * Cs), F), ((Ov, H), F), ((P, Cs), F), ((P, 3, Cv), F),
             ((P, 3, 3), F), ((320,), F), ((Os, 320), F), ((R, Cv), F))
 
+        # Two streams (forked / joined with events, so the pattern is captured into the hipGraph as parallel branches): the side
+        # stream builds the reverse neighbour lists while the main stream runs the point-level prelude
+        main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+        rev_range = torch.empty((2 * P,), dtype=torch.int32, device=dev)
+        rev_edge = torch.empty((E,), dtype=torch.int32, device=dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            call("svnet_knn_reverse_i32", _p(idx), B, N, k, _p(rev_range), _p(rev_edge), _stream())
+
         # ---- point-level prelude: BatchNorm reductions, gate gradient
         gy = torch.empty((P, Os), **f32)
         call("svnet_edgeblock_bwd_prelude_f32", _p(gs), _p(gv), _p(n_max), _p(n_min), _p(mv), _p(mvn), _p(coef), _p(sc1), _p(gate),
@@ -675,16 +684,12 @@ class EdgeBlock(torch.autograd.Function):
         d.dn_out, d.x_sign32, d.x_nz32 = _p(dn_out), _p(x_sign), _p(x_nz)
         # the neighbour's share of every edge goes to a message row and is summed over the reverse neighbour lists (gather):
         # float atomics are executed at the memory side on this part and were the bottleneck of the scatter formulation
-        rev_range = torch.empty((2 * P,), dtype=torch.int32, device=dev)
-        rev_edge = torch.empty((E,), dtype=torch.int32, device=dev)
-        call("svnet_knn_reverse_i32", _p(idx), B, N, k, _p(rev_range), _p(rev_edge), _stream())
         msg = torch.empty((E, _lib.lib().svnet_edgeblock_msg_stride(Cs, Cv, Ov)), **f32)
         dvc = torch.empty((P, 3, Ov), **f32)
         d.msg, d.ds_acc, d.dv_acc, d.dvc, d.dzc, d.dbeta_perm = _p(msg), _p(ds_acc), _p(dv_acc), _p(dvc), _p(dzc), _p(dbeta_perm)
         d.debug = _p(DEBUG_BUFFER)
         # the vector path (wave per point) and the scalar path (32-edge tiles) are independent: two streams, so that the
         # register/LDS-bound tile kernel and the light vector kernel share the CUs
-        main, side = torch.cuda.current_stream(dev), _side_stream(dev)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             d.parts = 1
