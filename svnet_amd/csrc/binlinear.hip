@@ -96,17 +96,31 @@ __global__ __launch_bounds__(256) void binlinear_fwd_kernel(const float* __restr
     for (int64_t tile = blockIdx.x / o_blocks; tile < tiles; tile += gridDim.x / o_blocks) {
         const int64_t row0 = tile * ROWS;
         const int rows = (int)min((int64_t)ROWS, M - row0);
-        // ---- phase 1: binarize + pack. wave w handles rows w, w+4, ...; 4 words' loads are in flight together
-        for (int r = wave; r < rows; r += 4) {
-            const float* xr = x + (row0 + r) * ldx;
-            for (int w0 = 0; w0 < KW; w0 += 4) {
+        // ---- phase 1: binarize + pack. wave w handles rows w, w+4, ... in batches of 4 words; the next batch's loads (possibly
+        // of the next row) are issued before the current batch is balloted, so 8 loads per lane are always in flight
+        {
+            int lr = wave, lw = 0;                                   // load cursor (row, first word of the batch)
+            float tn[4];
+#define SVNET_BL_LOAD()                                                                                   \
+    do {                                                                                                  \
+        if (lr < rows) {                                                                                  \
+            const float* xr_ = x + (row0 + lr) * ldx;                                                     \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                               \
+                const int k_ = (lw + u) * 64 + lane;                                                      \
+                const int kc_ = k_ < K ? k_ : K - 1; /* clamped: unconditional loads */                   \
+                tn[u] = xr_[kc_] + beta[kc_];                                                             \
+            }                                                                                             \
+        }                                                                                                 \
+    } while (0)
+            SVNET_BL_LOAD();
+            int r = wave, w0 = 0;                                    // use cursor
+            while (r < rows) {
                 float t[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int k = (w0 + u) * 64 + lane;
-                    const int kc = k < K ? k : K - 1;          // clamped: the loads stay unconditional and batch up
-                    t[u] = xr[kc] + beta[kc];
-                }
+                for (int u = 0; u < 4; ++u) t[u] = tn[u];
+                lw += 4;
+                if (lw >= KW) { lw = 0; lr += 4; }
+                SVNET_BL_LOAD();
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int w = w0 + u;
@@ -121,7 +135,10 @@ __global__ __launch_bounds__(256) void binlinear_fwd_kernel(const float* __restr
                         lt[r * KW + w] = st;
                     }
                 }
+                w0 += 4;
+                if (w0 >= KW) { w0 = 0; r += 4; }
             }
+#undef SVNET_BL_LOAD
         }
         __syncthreads();
         // ---- saved planes (training), written ROW-SLICED: word [tile*K + k] = bit r of column k for the tile's

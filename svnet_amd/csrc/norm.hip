@@ -67,7 +67,16 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
         const bool ok = c < C;
         double acc[2] = {0.0, 0.0};
         if (ok) {
-            for (int64_t r = r0 + rl; r < r1; r += RL) {
+            int64_t r = r0 + rl;
+            if (kind == 0) {   // four rows' loads in flight per thread (one at a time left the memory pipe three quarters empty)
+                for (; r + 3 * RL < r1; r += 4 * RL) {
+                    const float v0 = x[r * C + c], v1 = x[(r + RL) * C + c], v2 = x[(r + 2 * RL) * C + c], v3 = x[(r + 3 * RL) * C + c];
+                    acc[0] += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+                    acc[1] += ((double)v0 * (double)v0 + (double)v1 * (double)v1) + ((double)v2 * (double)v2 + (double)v3 * (double)v3);
+                }
+            }
+#pragma unroll 2
+            for (; r < r1; r += RL) {
                 float v;
                 if (kind == 0) {
                     v = x[r * C + c];
@@ -138,7 +147,20 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
         double acc[2] = {0.0, 0.0};
         if (ok) {
             const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
-            for (int64_t r = r0 + rl; r < r1; r += RL) {
+            int64_t r = r0 + rl;
+            for (; r + 3 * RL < r1; r += 4 * RL) {   // four rows' loads in flight per thread
+                float xv[4], gv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { xv[u] = x[(r + u * RL) * C + c]; gv[u] = g[(r + u * RL) * C + c]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float xh = (xv[u] - mu) * is;
+                    const float gp = gv[u] * act_grad(xh * ga + be, act, slope);
+                    acc[0] += (double)gp;
+                    acc[1] += (double)gp * (double)xh;
+                }
+            }
+            for (; r < r1; r += RL) {
                 const float xh = (x[r * C + c] - mu) * is;
                 const float gp = g[r * C + c] * act_grad(xh * ga + be, act, slope);
                 acc[0] += (double)gp;
@@ -207,6 +229,7 @@ __global__ __launch_bounds__(256) void vbn_bwd_reduce_kernel(const float* __rest
             const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
             int64_t cur_b = -1;
             float gsum = 0.f;
+#pragma unroll 2
             for (int64_t r = r0 + rl; r < r1; r += RL) {
                 const int64_t b = r / rpb;
                 if (b != cur_b) {
