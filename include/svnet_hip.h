@@ -321,6 +321,10 @@ int svnet_pool_fwd_f32(const float* x, int64_t outer, int64_t R, int64_t inner, 
                        void* workspace, size_t workspace_bytes, void* stream);
 int svnet_pool_bwd_f32(const float* g, const int32_t* argmax, int64_t outer, int64_t R, int64_t inner, int mode,
                        float* dx, void* stream);
+/* Backward of cat(max, mean) over the same axis (the classifier's global pooling, sv_dgcnn_cls.py:72-74) in one pass:
+ * g [outer, 2*inner] = [dL/dmax | dL/dmean], dx[o,r,i] = (argmax[o,i] == r ? g[o,i] : 0) + g[o,inner+i] / R.       */
+int svnet_pool_maxmean_bwd_f32(const float* g, const int32_t* argmax, int64_t outer, int64_t R, int64_t inner, float* dx,
+                               void* stream);
 
 /* ------------------------------------------------------------------ element-wise activations of the gate (sv_layers.py:156-161)
  * kind 1 = relu, 2 = sigmoid, 3 = leaky-relu(0.2).  Backward uses the OUTPUT y.                      */

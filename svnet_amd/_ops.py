@@ -463,6 +463,39 @@ class Pool(torch.autograd.Function):
         return dx, None, None
 
 
+class PoolMaxMean(torch.autograd.Function):
+    """cat(max, mean) over one axis of x (the global pooling of the classifiers, sv_dgcnn_cls.py:72-74): the two reductions
+    share the backward pass, so the gradient of x is written once instead of written twice and added."""
+
+    @staticmethod
+    def forward(ctx, x, dim):
+        _hip(x)
+        x = _f32c(x)
+        dim = dim % x.dim()
+        outer = 1
+        for d in x.shape[:dim]:
+            outer *= d
+        R = x.shape[dim]
+        inner = 1
+        for d in x.shape[dim + 1:]:
+            inner *= d
+        mx, arg = pool_raw(x, outer, R, inner, 0)
+        mean, _ = pool_raw(x, outer, R, inner, 1)
+        ctx.save_for_backward(arg)
+        ctx.meta = (outer, R, inner, x.shape)
+        out = torch.cat((mx, mean), dim=1)
+        return out.view(x.shape[:dim] + (2 * inner,)) if x.dim() - dim == 2 else out
+
+    @staticmethod
+    def backward(ctx, g):
+        outer, R, inner, xshape = ctx.meta
+        (arg,) = ctx.saved_tensors
+        g2 = _f32c(g).reshape(outer, 2 * inner)
+        dx = torch.empty(xshape, dtype=torch.float32, device=g.device)
+        call("svnet_pool_maxmean_bwd_f32", _p(g2), _p(arg), outer, R, inner, _p(dx), _stream())
+        return dx, None
+
+
 class Act(torch.autograd.Function):
     """kind 1 relu, 2 sigmoid, 3 leaky-relu(0.2) (sv_layers.py:156-161)."""
 

@@ -100,6 +100,35 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
     }
 }
 
+// Backward of [max | mean] over the same reduced axis in one pass: dx[o,r,i] = (argmax[o,i] == r ? g[o,i] : 0) + g[o,inner+i] / R.
+// grid (row chunks, outer); a thread keeps its columns' three operands in registers and streams the rows (no divisions).
+__global__ __launch_bounds__(256) void pool_maxmean_bwd_kernel(const float* __restrict__ g, const int32_t* __restrict__ argmax, int64_t R,
+                                                               int64_t inner, int64_t rows_per_chunk, float* __restrict__ dx) {
+    const int64_t o = blockIdx.y;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+    const float invR = 1.f / (float)R;
+    for (int64_t i0 = 0; i0 < inner; i0 += 4 * 256) {
+        float gx[4], gm[4];
+        int am[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + u * 256 + threadIdx.x;
+            const bool ok = i < inner;
+            gx[u] = ok ? g[o * 2 * inner + i] : 0.f;
+            gm[u] = ok ? g[o * 2 * inner + inner + i] * invR : 0.f;
+            am[u] = ok ? argmax[o * inner + i] : -1;
+        }
+        for (int64_t r = r0; r < r1; ++r) {
+            float* row = dx + (o * R + r) * inner;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = i0 + u * 256 + threadIdx.x;
+                if (i < inner) row[i] = gm[u] + (am[u] == (int32_t)r ? gx[u] : 0.f);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, int64_t n, int kind, float* __restrict__ y) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         const float v = x[e];
@@ -204,6 +233,21 @@ extern "C" int svnet_pool_bwd_f32(const float* g, const int32_t* argmax, int64_t
     hipLaunchKernelGGL(pool_bwd_kernel, dim3(svnet_grid(outer * R * inner, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, g, argmax,
                        outer, R, inner, mode, dx);
     SVNET_CHECK_LAUNCH("pool_bwd_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_pool_maxmean_bwd_f32(const float* g, const int32_t* argmax, int64_t outer, int64_t R, int64_t inner, float* dx,
+                                          void* stream) {
+    SVNET_REQUIRE(g && argmax && dx && outer >= 0 && R > 0 && inner > 0, SVNET_E_ARG, "svnet_pool_maxmean_bwd_f32: bad arguments");
+    SVNET_REQUIRE(outer <= 65535, SVNET_E_UNSUPPORTED, "svnet_pool_maxmean_bwd_f32: outer > 65535");
+    if (outer == 0) return SVNET_OK;
+    int64_t chunks = svnet_cdiv(256 * 16, outer);
+    if (chunks > R) chunks = R;
+    const int64_t rpc = svnet_cdiv(R, chunks);
+    chunks = svnet_cdiv(R, rpc);
+    hipLaunchKernelGGL(pool_maxmean_bwd_kernel, dim3((unsigned)chunks, (unsigned)outer), dim3(256), 0, (hipStream_t)stream, g, argmax, R,
+                       inner, rpc, dx);
+    SVNET_CHECK_LAUNCH("pool_maxmean_bwd_kernel");
     return SVNET_OK;
 }
 

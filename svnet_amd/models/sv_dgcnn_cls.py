@@ -43,7 +43,7 @@ class SV_DGCNN_CLS(nn.Module):
             pyramid.append(level)
 
         feat = self.svfuse(self.conv5(svcat(pyramid)))                 # [B,N,1022]
-        pooled = torch.cat((_ops.Pool.apply(feat, 1, 0), _ops.Pool.apply(feat, 1, 1)), dim=1)   # max | mean over points
+        pooled = _ops.PoolMaxMean.apply(feat, 1)                       # [max | mean] over points, one shared backward pass
 
         h = self.dp1(batch_norm_act(self.bn1, self.linear1(pooled), _ACT_LEAKY, 0.2))
         h = self.dp2(batch_norm_act(self.bn2, self.linear2(h), _ACT_LEAKY, 0.2))
