@@ -303,6 +303,12 @@ class SVFuse(nn.Module):
         self.trans_back = trans_back
         self.v2s = Vector2Scalar(v_dim, multi, binary=binary, trans_back=trans_back)
 
+    def parts(self, x):
+        """(s, Vector2Scalar(v)) without the concatenation, for consumers that reduce over the points right away
+        (pooling the parts and concatenating the small results equals pooling the concatenation)."""
+        s, v = x
+        return s, self.v2s(v)
+
     def forward(self, x):
         s, v = x
         if self.trans_back:
