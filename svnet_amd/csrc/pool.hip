@@ -292,6 +292,7 @@ __global__ __launch_bounds__(256) void gate_mlp_fwd_kernel(const float* __restri
     const float* g = gin + (size_t)b * Cin;
     for (int j = tid; j < H; j += blockDim.x) {
         float a = 0.f;
+#pragma unroll 8
         for (int c = 0; c < Cin; ++c) a = fmaf(g[c] * in_scale, W0[j * Cin + c], a);
         a = a > 0.f ? a : 0.f;
         hs[j] = a;
@@ -362,7 +363,8 @@ __global__ __launch_bounds__(256) void gate_mlp_bwd_sliced_kernel(const float* _
     for (int e = tid; e < B * H; e += blockDim.x) {
         const int b = e / H, j = e - b * H;
         float a = 0.f;
-        for (int o = 0; o < Ov; ++o) a = fmaf(dgp[b * Ov + o], W2[o * H + j], a);
+#pragma unroll 8
+        for (int o = 0; o < Ov; ++o) a = fmaf(dgp[b * Ov + o], W2[o * H + j], a);     // unrolled: 8 weight loads in flight
         dhp[e] = h[e] > 0.f ? a : 0.f;
     }
     __syncthreads();
@@ -371,16 +373,19 @@ __global__ __launch_bounds__(256) void gate_mlp_bwd_sliced_kernel(const float* _
         if (e < n0) {                                   // dW0[j,c] += sum_b dhp[b,j] * in_scale*gin[b,c]
             const int j = e / Cin, c = e - j * Cin;
             float a = 0.f;
+#pragma unroll 8
             for (int b = 0; b < B; ++b) a = fmaf(dhp[b * H + j], gin[(size_t)b * Cin + c], a);
             dW0[e] += a * in_scale;
         } else if (e < n0 + n1) {                       // dW2[o,j] += sum_b dgp[b,o] * h[b,j]
             const int q = e - n0, o = q / H, j = q - o * H;
             float a = 0.f;
+#pragma unroll 8
             for (int b = 0; b < B; ++b) a = fmaf(dgp[b * Ov + o], h[b * H + j], a);
             dW2[q] += a;
         } else {                                        // dgin[b,c] = out_scale * sum_j dhp[b,j] W0[j,c]
             const int q = e - n0 - n1, b = q / Cin, c = q - b * Cin;
             float a = 0.f;
+#pragma unroll 8
             for (int j = 0; j < H; ++j) a = fmaf(dhp[b * H + j], W0[j * Cin + c], a);
             dgin[q] = a * out_scale;
         }
