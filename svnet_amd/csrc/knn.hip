@@ -207,16 +207,20 @@ __device__ __forceinline__ void wave_sort_desc(float& v, int& j, int lane) {
     sort_step<64, 2>(v, j, lane); sort_step<64, 1>(v, j, lane);
 }
 // T candidates per lane (64*T >= N), Q query rows per wave, 4 waves per workgroup.
-template <int T, int Q>
+// STAGE: the four waves of a workgroup share the candidate rows through LDS (CC channels at a time, N % 4 == 0): every wave
+// needs the whole [C, N] table of its cloud, so without sharing the L2 -> CU traffic is 4x what the arithmetic can hide.
+constexpr int KNN_CC = 8;
+template <int T, int Q, bool STAGE>
 __global__ __launch_bounds__(256) void knn_main_kernel(const float* __restrict__ xT, const float* __restrict__ xx,
                                                        int N, int C, int k, int64_t* __restrict__ idx_out) {
     __shared__ float cand_v[4 * 64];
     __shared__ int cand_j[4 * 64];
+    extern __shared__ __attribute__((aligned(16))) float rows[];      // STAGE: [KNN_CC][64 * T]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int b = blockIdx.y;
     const int q0 = (blockIdx.x * 4 + wave) * Q;
-    if (q0 >= N) return;  // wave-uniform (no workgroup barriers below: the LDS slices are per wave)
+    if (!STAGE && q0 >= N) return;  // wave-uniform (no workgroup barriers in the unstaged variant: the LDS slices are per wave)
 
     const float* __restrict__ xb = xT + (size_t)b * C * N;
     const float* __restrict__ xxb = xx + (size_t)b * N;
@@ -231,6 +235,45 @@ __global__ __launch_bounds__(256) void knn_main_kernel(const float* __restrict__
 #pragma unroll
     for (int q = 0; q < Q; ++q) qi[q] = min(q0 + q, N - 1);
 
+    if (STAGE) {
+        // chunk i+1 travels global -> registers while chunk i is consumed from LDS; the FMA chain over c keeps its order
+        constexpr int NP = 64 * T;
+        constexpr int F4 = (KNN_CC * NP / 4 / 256) > 0 ? (KNN_CC * NP / 4 / 256) : 1;   // float4 per thread per chunk (STAGE needs T >= 4)
+        float4 stg[F4];
+        const int n4 = N >> 2;
+#define SVNET_KNN_FETCH(C0)                                                                         \
+    do {                                                                                            \
+        _Pragma("unroll") for (int u = 0; u < F4; ++u) {                                            \
+            const int e_ = u * 256 + threadIdx.x;                                                   \
+            const int rw_ = e_ / (NP / 4), c4_ = e_ - rw_ * (NP / 4);                               \
+            stg[u] = ((C0) + rw_ < C && c4_ < n4) ? *reinterpret_cast<const float4*>(xb + (size_t)((C0) + rw_) * N + 4 * c4_) \
+                                                   : make_float4(0.f, 0.f, 0.f, 0.f);               \
+        }                                                                                           \
+    } while (0)
+        SVNET_KNN_FETCH(0);
+        for (int c0 = 0; c0 < C; c0 += KNN_CC) {
+            __syncthreads();                                         // the previous chunk has been consumed
+#pragma unroll
+            for (int u = 0; u < F4; ++u) *reinterpret_cast<float4*>(&rows[4 * (u * 256 + threadIdx.x)]) = stg[u];
+            __syncthreads();
+            if (c0 + KNN_CC < C) SVNET_KNN_FETCH(c0 + KNN_CC);
+            const int cc_end = min(KNN_CC, C - c0);
+            for (int cc = 0; cc < cc_end; ++cc) {
+                const float* row = rows + cc * NP;
+                float cand[T], qv[Q];
+#pragma unroll
+                for (int t = 0; t < T; ++t) cand[t] = row[lane + 64 * t];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) qv[q] = row[qi[q]];
+#pragma unroll
+                for (int q = 0; q < Q; ++q)
+#pragma unroll
+                    for (int t = 0; t < T; ++t) acc[q][t] = __builtin_fmaf(qv[q], cand[t], acc[q][t]);
+            }
+        }
+#undef SVNET_KNN_FETCH
+        if (q0 >= N) return;                                         // idle waves only helped with the staging
+    } else {
     // channel c+1's candidate row and query values are requested before channel c's FMAs (the chain over c is what fixes
     // the rounding, so the loop cannot be reordered, only overlapped)
     int jc[T];
@@ -258,6 +301,7 @@ __global__ __launch_bounds__(256) void knn_main_kernel(const float* __restrict__
         for (int q = 0; q < Q; ++q)
 #pragma unroll
             for (int t = 0; t < T; ++t) acc[q][t] = __builtin_fmaf(qv[q], cand[t], acc[q][t]);
+    }
     }
 
     float xxj[T];
@@ -334,7 +378,11 @@ __global__ __launch_bounds__(256) void knn_main_kernel(const float* __restrict__
 template <int T, int Q>
 void launch_main(const float* xT, const float* xx, int64_t B, int N, int C, int k, int64_t* idx, hipStream_t st) {
     dim3 grid((unsigned)svnet_cdiv(N, 4 * Q), (unsigned)B);
-    hipLaunchKernelGGL((knn_main_kernel<T, Q>), grid, dim3(256), 0, st, xT, xx, N, C, k, idx);
+    constexpr size_t stage_bytes = (size_t)KNN_CC * 64 * T * sizeof(float);
+    if (T >= 4 && T <= 16 && (N & 3) == 0 && C >= 8)       // (T < 4: the staging chunk would not fill the 256 threads' float4 slots)
+        hipLaunchKernelGGL((knn_main_kernel<T, Q, (T >= 4 && T <= 16)>), grid, dim3(256), stage_bytes, st, xT, xx, N, C, k, idx);
+    else
+        hipLaunchKernelGGL((knn_main_kernel<T, Q, false>), grid, dim3(256), 0, st, xT, xx, N, C, k, idx);
 }
 
 }  // namespace
