@@ -68,9 +68,11 @@ __device__ __forceinline__ void split3_frag(const float (&x)[8], bf16x8& fh, bf1
 }
 
 // ---- cross-lane sums without the LDS crossbar (DPP modifiers + the gfx950 half / row swaps)
+// (bound_ctrl for the controls that read a valid lane everywhere: the `old` operand is then dead and the DPP read folds into
+//  the consuming add instead of costing a v_mov for `old` plus a v_mov_dpp)
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ float dpp_get(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF));
 }
 constexpr int DPP_QUAD_1032 = 0xB1, DPP_QUAD_2301 = 0x4E, DPP_ROW_ROR8 = 0x128, DPP_ROW_MIRROR = 0x140, DPP_ROW_HALF_MIRROR = 0x141,
               DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
@@ -296,24 +298,28 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_vec_kernel(VecArgs va) {
 // What one lane needs for one edge row in phase C.  The row index is wave-uniform (readfirstlane'd wave id), so gp / gj /
 // the zz rows go through scalar loads and SGPR-based addressing.
 struct EdgeIn {
-    int64_t gp, gj, b;
+    uint32_t gp, gj;                              // global point ids (P * 384 < 2^32 is checked on the host: 32-bit row offsets)
     bool valid;
     float vi0, vi1, vi2, vj0, vj1, vj2;           // lane c2 < 2Cv (vj: diff lanes only)
     float z0, z1, z2, z3, z4, z5, z6, z7, z8;     // z[d*3+jz] = Zp_j - Zp_i + Zq_i
 };
 
-// Row cursor of a wave: edge id, its point / cloud / slot, advanced one edge at a time (no 64-bit divisions in the loop).
+// Row cursor of a wave: edge id, its point / cloud / slot, advanced one edge at a time (no divisions, 32-bit scalar math: the
+// CU's single scalar unit is shared by its four SIMDs and was the busiest unit of this kernel).
 struct EdgeCursor {
-    int64_t e, gp, b;
+    int64_t e;
+    uint32_t gp, b;
     int t, pin;
 };
 __device__ __forceinline__ void cursor_init(const svnet_edgeblock_bwd_desc& d, int64_t e, EdgeCursor& c) {
     const int k = (int)d.k;
     c.e = e;
-    c.gp = e / k;
-    c.t = (int)(e - c.gp * k);
-    c.b = c.gp / d.N;
-    c.pin = (int)(c.gp - c.b * d.N);
+    const int64_t gp = e / k;
+    c.gp = (uint32_t)gp;
+    c.t = (int)(e - gp * k);
+    const int64_t b = gp / d.N;
+    c.b = (uint32_t)b;
+    c.pin = (int)(gp - b * d.N);
 }
 __device__ __forceinline__ void cursor_next(const svnet_edgeblock_bwd_desc& d, EdgeCursor& c) {
     ++c.e;
@@ -325,33 +331,32 @@ __device__ __forceinline__ void cursor_next(const svnet_edgeblock_bwd_desc& d, E
 }
 
 // jloc: the edge's neighbour id (wave-uniform, from the wave's pre-loaded id vector)
-__device__ __forceinline__ void load_edge(const svnet_edgeblock_bwd_desc& d, const EdgeCursor& c, int64_t jloc, int64_t E, int lane,
+__device__ __forceinline__ void load_edge(const svnet_edgeblock_bwd_desc& d, const EdgeCursor& c, int jloc, int64_t E, int lane,
                                           bool v2_lane, int cm, EdgeIn& in) {
-    const int Cv = d.Cv;
+    const uint32_t Cv = (uint32_t)d.Cv, N = (uint32_t)d.N;
     in.valid = c.e < E;
     if (!in.valid) return;
     in.gp = c.gp;
-    in.b = c.b;
-    if ((uint64_t)jloc >= (uint64_t)d.N) {  // corrupted neighbour id: never dereference it
+    if ((uint32_t)jloc >= N) {  // corrupted neighbour id: never dereference it
         if (d.debug && lane == 0) {
             if (atomicAdd(reinterpret_cast<unsigned long long*>(d.debug), 1ull) == 0ull) { d.debug[1] = c.e; d.debug[2] = jloc; d.debug[3] = d.N; }
         }
         in.valid = false;
         return;
     }
-    in.gj = in.b * d.N + jloc;
-    const int64_t gp = in.gp, gj = in.gj;
+    in.gj = c.b * N + (uint32_t)jloc;
     // clamped lane indices: every lane issues every load (no exec-masked branches, loads go out back to back);
     // lanes outside a channel range read a valid neighbour element that is masked where it is consumed
-    const int ld = min(lane, Cv - 1), lc = v2_lane ? cm : 0;
-    in.vi0 = d.v[(gp * 3 + 0) * Cv + lc];
-    in.vi1 = d.v[(gp * 3 + 1) * Cv + lc];
-    in.vi2 = d.v[(gp * 3 + 2) * Cv + lc];
-    in.vj0 = d.v[(gj * 3 + 0) * Cv + ld];
-    in.vj1 = d.v[(gj * 3 + 1) * Cv + ld];
-    in.vj2 = d.v[(gj * 3 + 2) * Cv + ld];
-    const float* zi = d.zz + gp * 18;
-    const float* zj = d.zz + gj * 18;
+    const uint32_t ld = (uint32_t)min(lane, (int)Cv - 1), lc = v2_lane ? (uint32_t)cm : 0u;
+    const uint32_t oi = in.gp * 3u * Cv + lc, oj = in.gj * 3u * Cv + ld;
+    in.vi0 = d.v[oi];
+    in.vi1 = d.v[oi + Cv];
+    in.vi2 = d.v[oi + 2u * Cv];
+    in.vj0 = d.v[oj];
+    in.vj1 = d.v[oj + Cv];
+    in.vj2 = d.v[oj + 2u * Cv];
+    const float* zi = d.zz + in.gp * 18u;
+    const float* zj = d.zz + in.gj * 18u;
     in.z0 = zj[0] + (zi[3] - zi[0]);    in.z1 = zj[1] + (zi[4] - zi[1]);    in.z2 = zj[2] + (zi[5] - zi[2]);
     in.z3 = zj[6] + (zi[9] - zi[6]);    in.z4 = zj[7] + (zi[10] - zi[7]);   in.z5 = zj[8] + (zi[11] - zi[8]);
     in.z6 = zj[12] + (zi[15] - zi[12]); in.z7 = zj[13] + (zi[16] - zi[13]); in.z8 = zj[14] + (zi[17] - zi[14]);
@@ -647,7 +652,9 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
     PHASE_MARK(3);   // phase C1
     // ================= phase C2 (lanes = vector channels, one edge per wave iteration): v2s backward =================
     {
-        int64_t cur_p = -1;
+        uint32_t cur_p = 0xFFFFFFFFu;               // "no point yet"
+        const uint32_t uCv = (uint32_t)Cv;
+        float* const mrow0 = d.msg + ew * R + Cs;   // message row of this wave's first edge (the only 64-bit product)
         float cvd0 = 0.f, cvd1 = 0.f, cvd2 = 0.f;   // centre part of dv (diff lanes carry -sum, centre lanes +sum)
         float czq = 0.f, czq8 = 0.f;                // centre sums of dL/dz: packed (group g of 8 lanes: entry bitreverse3(g)), entry 8
         const int zq_idx = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2);   // bitreverse3(lane >> 3)
@@ -657,12 +664,13 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
 #define SVNET_FLUSH_POINT(p)                                                                                      \
     do {                                                                                                          \
         if (v2_lane) {                                                                                            \
-            ATOMIC_ADD(&d.dv_acc[((p) * 3 + 0) * Cv + cm], cvd0);                                                  \
-            ATOMIC_ADD(&d.dv_acc[((p) * 3 + 1) * Cv + cm], cvd1);                                                  \
-            ATOMIC_ADD(&d.dv_acc[((p) * 3 + 2) * Cv + cm], cvd2);                                                  \
+            float* a_ = d.dv_acc + ((p) * 3u * uCv + (uint32_t)cm);                                                \
+            ATOMIC_ADD(a_, cvd0);                                                                                  \
+            ATOMIC_ADD(a_ + uCv, cvd1);                                                                            \
+            ATOMIC_ADD(a_ + 2u * uCv, cvd2);                                                                       \
         }                                                                                                         \
-        if (zq_writer) ATOMIC_ADD(&d.dzc[(p) * 9 + zq_idx], czq);                                                  \
-        if (lane == 63) ATOMIC_ADD(&d.dzc[(p) * 9 + 8], czq8);                                                     \
+        if (zq_writer) ATOMIC_ADD(&d.dzc[(p) * 9u + (uint32_t)zq_idx], czq);                                       \
+        if (lane == 63) ATOMIC_ADD(&d.dzc[(p) * 9u + 8u], czq8);                                                   \
     } while (0)
 
         // edge rows are requested two iterations ahead (a ring of four with compile-time slots: no register copies)
@@ -685,9 +693,9 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
             }
             const EdgeIn& in = q[u];
             if (!in.valid) continue;
-            const int64_t gp = in.gp;
+            const uint32_t gp = in.gp;
             if (gp != cur_p) {
-                if (cur_p >= 0) SVNET_FLUSH_POINT(cur_p);
+                if (cur_p != 0xFFFFFFFFu) SVNET_FLUSH_POINT(cur_p);
                 cur_p = gp;
                 cvd0 = cvd1 = cvd2 = 0.f;
                 czq = czq8 = 0.f;
@@ -712,14 +720,14 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
             else if (v2_lane) { cvd0 += dve0; cvd1 += dve1; cvd2 += dve2; }
             // ---- the neighbour's share: plain stores into the edge's message row
             {
-                float* m = d.msg + (ew + rr) * R + Cs;
+                float* m = mrow0 + (uint32_t)rr * (uint32_t)R;
                 if (diff_lane) { m[lane] = dve0; m[Cv + lane] = dve1; m[2 * Cv + lane] = dve2; }
                 if (zq_writer) m[3 * Cv + zq_idx] = dzp;
                 if (lane == 63) m[3 * Cv + 8] = dz8;
             }
         }
         }
-        if (cur_p >= 0) SVNET_FLUSH_POINT(cur_p);
+        if (cur_p != 0xFFFFFFFFu) SVNET_FLUSH_POINT(cur_p);
 #undef SVNET_FLUSH_POINT
 #undef SVNET_LOAD_BFR
     }
@@ -772,6 +780,7 @@ extern "C" int svnet_edgeblock_bwd_f32(const svnet_edgeblock_bwd_desc* desc, voi
                   SVNET_E_ARG, "svnet_edgeblock_bwd_f32: null pointer");
     SVNET_REQUIRE(d.B >= 0 && d.N > 0 && d.k > 0 && d.k <= 64, SVNET_E_ARG, "svnet_edgeblock_bwd_f32: bad sizes (k <= 64)");
     SVNET_REQUIRE((d.Os & (d.Os - 1)) == 0, SVNET_E_UNSUPPORTED, "svnet_edgeblock_bwd_f32: Os must be a power of two (8..128)");
+    SVNET_REQUIRE(d.B * d.N * 384 < ((int64_t)1 << 32), SVNET_E_UNSUPPORTED, "svnet_edgeblock_bwd_f32: more than 11 M points (32-bit row offsets)");
     SVNET_REQUIRE(d.Cs > 0 && d.Cs <= 64 && d.Cv > 0 && 2 * d.Cv <= 64 && d.Os > 0 && d.Os <= 128 && d.Os % 8 == 0 && d.Ov > 0 &&
                       d.Ov <= 64, SVNET_E_UNSUPPORTED, "svnet_edgeblock_bwd_f32: channel counts outside Cs<=64, 2Cv<=64, Os<=128 (mult of 8), Ov<=64");
     const int64_t E = d.B * d.N * d.k;
