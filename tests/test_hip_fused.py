@@ -151,3 +151,56 @@ def test_fused_first_layer_matches_layerwise_and_oracle(cfg, train, hip_device):
         s0 = sv_ref.vector2scalar(ve, P, "init_scalar")
         os_, ov = sv_ref.svpool(sv_ref.svblock((s0, ve), P, "conv1", False, ctx))
     compare_case({"out0": res[True]["out0"], "out1": res[True]["out1"]}, {"out0": os_.numpy(), "out1": ov.numpy()}, 1e-4, "fused first layer vs oracle")
+
+
+# ----------------------------------------------------------------------------- pieces of the fused backward, through the C ABI
+
+def test_knn_reverse_lists_are_a_permutation_of_the_edges(hip_device):
+    """svnet_knn_reverse_i32: every edge e = i*k + t appears exactly once, in the list of the point idx[e] names
+    (cloud-local ids, sv_util.py:19-25), and edges with an out-of-range id appear nowhere."""
+    from svnet_amd import _lib
+    from svnet_amd._ops import _p, _stream, call
+    B, N, k = 3, 200, 7
+    g = torch.Generator().manual_seed(5)
+    idx = torch.randint(0, N, (B, N, k), generator=g, dtype=torch.int64)
+    idx[1, 17, 3] = N + 5                                     # a corrupted id
+    idx[2, 0, 0] = -1
+    d_idx = idx.to(hip_device)
+    P, E = B * N, B * N * k
+    rng = torch.empty(2 * P, dtype=torch.int32, device=hip_device)
+    red = torch.full((E,), -7, dtype=torch.int32, device=hip_device)
+    call("svnet_knn_reverse_i32", _p(d_idx), B, N, k, _p(rng), _p(red), _stream())
+    rng, red = rng.cpu().numpy().reshape(P, 2), red.cpu().numpy()
+    flat = idx.reshape(-1).numpy()
+    seen = np.zeros(E, dtype=np.int64)
+    for j in range(P):
+        b = j // N
+        for e in red[rng[j, 0]:rng[j, 1]]:
+            assert 0 <= e < E and e // (N * k) == b            # an edge of the same cloud ...
+            assert flat[e] == j - b * N                         # ... that points at j
+            seen[e] += 1
+    valid = (flat >= 0) & (flat < N)
+    assert np.array_equal(seen, valid.astype(np.int64))
+
+
+def test_pool_max_mean_matches_torch(hip_device):
+    """_ops.PoolMaxMean = cat(max, mean) over the points (sv_dgcnn_cls.py:72-74), first index on ties, one shared backward."""
+    from svnet_amd import _ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 300, 70, generator=g)
+    x[1, 5] = x[1, 200]                                        # ties: the first index must receive the gradient
+    w = torch.randn(4, 140, generator=g)
+    xd = x.to(hip_device).requires_grad_(True)
+    out = _ops.PoolMaxMean.apply(xd, 1)
+    (out * w.to(hip_device)).sum().backward()
+    xr = x.clone().requires_grad_(True)
+    ref = torch.cat((xr.max(dim=1).values, xr.mean(dim=1)), dim=1)
+    # torch's max backward sends the gradient to ONE arg-max; build the first-index rule explicitly
+    arg = torch.zeros(4, 70, dtype=torch.int64)
+    for b in range(4):
+        for c in range(70):
+            arg[b, c] = int(torch.nonzero(x[b, :, c] == x[b, :, c].max())[0])
+    gref = (w[:, 70:] / 300.0).unsqueeze(1).expand(4, 300, 70).clone()
+    gref.scatter_add_(1, arg.unsqueeze(1), w[:, :70].unsqueeze(1))
+    assert torch.allclose(out.detach().cpu(), ref.detach(), atol=1e-6, rtol=1e-6)
+    assert torch.allclose(xd.grad.cpu(), gref, atol=1e-6, rtol=1e-6)
