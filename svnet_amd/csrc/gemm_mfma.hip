@@ -243,6 +243,7 @@ struct TnArgs {
     int lds_reduce;                     // combine the row-splitting waves in LDS before the global atomics
     float alpha;
     uint32_t qmask;                     // ternary B: bit t = q tile t (32 columns) may be non-zero; cleared tiles are skipped
+    uint32_t qlist;                     // != 0: the workgroup's NQ tiles are the tile ids packed here, 4 bits each (+1; 0 = none)
 };
 
 // NQ 32-wide q tiles per workgroup (blockIdx.z picks the group).  The 4 waves cover `ptw` p tiles (1, 2 or 4 per
@@ -365,6 +366,8 @@ __global__ __launch_bounds__(256, 2) void mfma_tn_tern_kernel(TnArgs a) {
     const int ptw = a.ptiles_per_block;                      // 1, 2 or 4
     const int p0 = (blockIdx.y * ptw + (wave % ptw)) * 32;
     const int q0 = blockIdx.z * (NQ * 32);
+    // column tile handled as slot t: consecutive tiles of this z group, or (compacted launch) the t-th tile in use
+#define SVNET_QT(t) (a.qlist ? (int)((a.qlist >> (4 * (t))) & 15u) - 1 : (q0 >> 5) + (t))
     const bool live = p0 < a.P;                              // wave-uniform
     const int nsub = 4 / ptw, sub = wave / ptw;
     const int64_t rows_sub = ((a.rows_per_block / nsub + 63) >> 6) << 6;   // multiple of 64
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void mfma_tn_tern_kernel(TnArgs a) {
 #define SVNET_TN_WORDS(M64, SG, NZ)                                                      \
     do {                                                                                 \
         _Pragma("unroll") for (int t = 0; t < NQ; ++t) {                                 \
-            const int q_ = min(q0 + t * 32 + r, a.Q - 1);                                \
+            const int q_ = min(max(SVNET_QT(t), 0) * 32 + r, a.Q - 1);                   \
             SG[t] = a.b_sign[((M64) >> 6) * a.Q + q_];                                   \
             NZ[t] = a.b_nz[((M64) >> 6) * a.Q + q_];                                     \
         }                                                                                \
@@ -417,8 +420,9 @@ __global__ __launch_bounds__(256, 2) void mfma_tn_tern_kernel(TnArgs a) {
                 const int sh = s16 + 8 * h;
 #pragma unroll
                 for (int t = 0; t < NQ; ++t) {
-                    if (q0 + t * 32 >= a.Q) break;  // uniform
-                    if (!((a.qmask >> ((q0 >> 5) + t)) & 1u)) continue;   // a tile of padding columns (uniform)
+                    const int qt = SVNET_QT(t);
+                    if (qt < 0 || qt * 32 >= a.Q) continue;               // no such tile (uniform)
+                    if (!((a.qmask >> qt) & 1u)) continue;                // a tile of padding columns (uniform)
                     const uint32_t nzb = (uint32_t)(wnz[t] >> sh) & 0xFFu;
                     const uint32_t ngb = nzb & ~(uint32_t)(wsg[t] >> sh);
                     const uint4 mg = *reinterpret_cast<const uint4*>(&lut_mag[nzb * 4]);
@@ -455,8 +459,9 @@ __global__ __launch_bounds__(256, 2) void mfma_tn_tern_kernel(TnArgs a) {
     if (!live) return;
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
-        const int q = q0 + t * 32 + r;  // D col = lane & 31  <-> B operand column (q)
-        if (q < a.Q && ((a.qmask >> ((q0 >> 5) + t)) & 1u)) {
+        const int qt = SVNET_QT(t);
+        const int q = qt * 32 + r;      // D col = lane & 31  <-> B operand column (q)
+        if (qt >= 0 && q < a.Q && ((a.qmask >> qt) & 1u)) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int pp = p0 + (i & 3) + 8 * (i >> 2) + 4 * h;  // D row <-> A operand row (p)
@@ -465,6 +470,8 @@ __global__ __launch_bounds__(256, 2) void mfma_tn_tern_kernel(TnArgs a) {
         }
     }
 }
+
+#undef SVNET_QT
 
 __global__ void zero2d_kernel(float* C, int64_t P, int64_t Q, int64_t ps, int64_t qs) {
     const int64_t total = P * Q;
@@ -492,7 +499,16 @@ template <int NQ, int BMODE>
 void launch_tn(TnArgs a, hipStream_t st) {
     const int ptiles = (int)svnet_cdiv(a.P, 32);
     a.ptiles_per_block = ptiles >= 3 ? 4 : ptiles;
-    const int gy = (int)svnet_cdiv(ptiles, a.ptiles_per_block), gz = (int)svnet_cdiv(a.Q, NQ * 32);
+    int gz = (int)svnet_cdiv(a.Q, NQ * 32);
+    a.qlist = 0;
+    if (BMODE == 1 && a.qmask != 0xFFFFFFFFu) {   // few tiles in use: one z group over exactly those (the A split is then shared)
+        int used = 0;
+        uint32_t list = 0;
+        for (int t = 0; t < 15 && t * 32 < a.Q; ++t)
+            if ((a.qmask >> t) & 1u) { if (used < 8) list |= (uint32_t)(t + 1) << (4 * used); ++used; }
+        if (used > 0 && used <= NQ) { a.qlist = list; gz = 1; }
+    }
+    const int gy = (int)svnet_cdiv(ptiles, a.ptiles_per_block);
     int64_t want = svnet_cdiv(1024, (int64_t)gy * gz);               // ~4 workgroups per CU in total
     int64_t rpb = svnet_cdiv(svnet_cdiv(a.M, want), 256) * 256;
     if (rpb < 256) rpb = 256;
