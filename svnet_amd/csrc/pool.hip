@@ -342,56 +342,6 @@ __global__ __launch_bounds__(256) void gate_mlp_bwd_kernel(const float* __restri
     }
 }
 
-// Same backward for batches that fit LDS (B*(Ov+H) floats <= 60 KB): every workgroup recomputes the two small per-cloud
-// vectors dgp [B,Ov], dhp [B,H] into LDS (cheap) and then owns a slice of the outputs, each a plain sum over the clouds:
-// no atomics, no zero-fill dependence, tens of workgroups instead of B.
-__global__ __launch_bounds__(256) void gate_mlp_bwd_sliced_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
-                                                                  const float* __restrict__ h, const float* __restrict__ gin,
-                                                                  float in_scale, const float* __restrict__ W0,
-                                                                  const float* __restrict__ W2, int B, int Cin, int H, int Ov,
-                                                                  float out_scale, float* __restrict__ dgin, float* __restrict__ dW0,
-                                                                  float* __restrict__ dW2) {
-    extern __shared__ float gl[];
-    float* dgp = gl;                 // [B][Ov]
-    float* dhp = gl + B * Ov;        // [B][H]
-    const int tid = threadIdx.x;
-    for (int e = tid; e < B * Ov; e += blockDim.x) {
-        const float gt = gate[e];
-        dgp[e] = dgate[e] * gt * (1.f - gt);
-    }
-    __syncthreads();
-    for (int e = tid; e < B * H; e += blockDim.x) {
-        const int b = e / H, j = e - b * H;
-        float a = 0.f;
-#pragma unroll 8
-        for (int o = 0; o < Ov; ++o) a = fmaf(dgp[b * Ov + o], W2[o * H + j], a);     // unrolled: 8 weight loads in flight
-        dhp[e] = h[e] > 0.f ? a : 0.f;
-    }
-    __syncthreads();
-    const int n0 = H * Cin, n1 = Ov * H, n2 = dgin ? B * Cin : 0;
-    for (int e = blockIdx.x * blockDim.x + tid; e < n0 + n1 + n2; e += gridDim.x * blockDim.x) {
-        if (e < n0) {                                   // dW0[j,c] += sum_b dhp[b,j] * in_scale*gin[b,c]
-            const int j = e / Cin, c = e - j * Cin;
-            float a = 0.f;
-#pragma unroll 8
-            for (int b = 0; b < B; ++b) a = fmaf(dhp[b * H + j], gin[(size_t)b * Cin + c], a);
-            dW0[e] += a * in_scale;
-        } else if (e < n0 + n1) {                       // dW2[o,j] += sum_b dgp[b,o] * h[b,j]
-            const int q = e - n0, o = q / H, j = q - o * H;
-            float a = 0.f;
-#pragma unroll 8
-            for (int b = 0; b < B; ++b) a = fmaf(dgp[b * Ov + o], h[b * H + j], a);
-            dW2[q] += a;
-        } else {                                        // dgin[b,c] = out_scale * sum_j dhp[b,j] W0[j,c]
-            const int q = e - n0 - n1, b = q / Cin, c = q - b * Cin;
-            float a = 0.f;
-#pragma unroll 8
-            for (int j = 0; j < H; ++j) a = fmaf(dhp[b * H + j], W0[j * Cin + c], a);
-            dgin[q] = a * out_scale;
-        }
-    }
-}
-
 }  // namespace
 
 extern "C" int svnet_gate_mlp_fwd_f32(const float* gin, float in_scale, const float* W0, const float* W2, int64_t B, int64_t Cin,
@@ -412,17 +362,6 @@ extern "C" int svnet_gate_mlp_bwd_f32(const float* dgate, const float* gate, con
                   "svnet_gate_mlp_bwd_f32: bad arguments");
     SVNET_REQUIRE(H <= 256 && Ov <= 256, SVNET_E_UNSUPPORTED, "svnet_gate_mlp_bwd_f32: H, Ov must be <= 256");
     if (B == 0) return SVNET_OK;
-    const size_t lds = (size_t)B * (Ov + H) * sizeof(float);
-    if (lds <= 60 * 1024) {
-        const int64_t outs = H * Cin + Ov * H + (dgin ? B * Cin : 0);
-        int64_t blocks = svnet_cdiv(outs, 256 * 8);
-        if (blocks > 64) blocks = 64;
-        if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(gate_mlp_bwd_sliced_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, dgate, gate, h, gin,
-                           in_scale, W0, W2, (int)B, (int)Cin, (int)H, (int)Ov, out_scale, dgin, dW0, dW2);
-        SVNET_CHECK_LAUNCH("gate_mlp_bwd_sliced_kernel");
-        return SVNET_OK;
-    }
     hipLaunchKernelGGL(gate_mlp_bwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, dgate, gate, h, gin, in_scale, W0, W2,
                        (int)Cin, (int)H, (int)Ov, out_scale, dgin, dW0, dW2);
     SVNET_CHECK_LAUNCH("gate_mlp_bwd_kernel");
