@@ -509,7 +509,10 @@ void launch_tn(TnArgs a, hipStream_t st) {
         if (used > 0 && used <= NQ) { a.qlist = list; gz = 1; }
     }
     const int gy = (int)svnet_cdiv(ptiles, a.ptiles_per_block);
-    int64_t want = svnet_cdiv(1024, (int64_t)gy * gz);               // ~4 workgroups per CU in total
+    // ~4 workgroups per CU in total; 2 when the output is large (every row split ends in P*Q float atomics, which the memory
+    // side executes at ~1 TB/s: conv5's 512 x 505 gradient spent half its time there with 128 splits)
+    const int64_t target = ((int64_t)a.P * a.Q >= 128 * 1024) ? 512 : 1024;
+    int64_t want = svnet_cdiv(target, (int64_t)gy * gz);
     int64_t rpb = svnet_cdiv(svnet_cdiv(a.M, want), 256) * 256;
     if (rpb < 256) rpb = 256;
     a.rows_per_block = rpb;
