@@ -69,10 +69,12 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
         if (ok) {
             int64_t r = r0 + rl;
             if (kind == 0) {   // four rows' loads in flight per thread (one at a time left the memory pipe three quarters empty)
-                for (; r + 3 * RL < r1; r += 4 * RL) {
-                    const float v0 = x[r * C + c], v1 = x[(r + RL) * C + c], v2 = x[(r + 2 * RL) * C + c], v3 = x[(r + 3 * RL) * C + c];
-                    acc[0] += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
-                    acc[1] += ((double)v0 * (double)v0 + (double)v1 * (double)v1) + ((double)v2 * (double)v2 + (double)v3 * (double)v3);
+                for (; r + 7 * RL < r1; r += 8 * RL) {
+                    float vv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) vv[u] = x[(r + u * RL) * C + c];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { acc[0] += (double)vv[u]; acc[1] += (double)vv[u] * (double)vv[u]; }
                 }
             }
 #pragma unroll 2
@@ -148,12 +150,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
         if (ok) {
             const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
             int64_t r = r0 + rl;
-            for (; r + 3 * RL < r1; r += 4 * RL) {   // four rows' loads in flight per thread
-                float xv[4], gv[4];
+            for (; r + 7 * RL < r1; r += 8 * RL) {   // eight rows' loads (16 values) in flight per thread
+                float xv[8], gv[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { xv[u] = x[(r + u * RL) * C + c]; gv[u] = g[(r + u * RL) * C + c]; }
+                for (int u = 0; u < 8; ++u) { xv[u] = x[(r + u * RL) * C + c]; gv[u] = g[(r + u * RL) * C + c]; }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 8; ++u) {
                     const float xh = (xv[u] - mu) * is;
                     const float gp = gv[u] * act_grad(xh * ga + be, act, slope);
                     acc[0] += (double)gp;
@@ -227,27 +229,44 @@ __global__ __launch_bounds__(256) void vbn_bwd_reduce_kernel(const float* __rest
         double acc[2] = {0.0, 0.0};
         if (ok) {
             const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
-            int64_t cur_b = -1;
-            float gsum = 0.f;
-#pragma unroll 2
-            for (int64_t r = r0 + rl; r < r1; r += RL) {
-                const int64_t b = r / rpb;
-                if (b != cur_b) {
+            int64_t cur_b = -1, b_end = 0;               // rows [.., b_end) belong to cloud cur_b
+            float gsum = 0.f, gt = 1.f;
+            int64_t r = r0 + rl;
+            while (r < r1) {
+                if (r >= b_end) {                         // next cloud: one division per cloud, not per row
                     if (cur_b >= 0 && dgate) atomicAdd(&dgate[cur_b * C + c], gsum);
-                    cur_b = b;
+                    cur_b = r / rpb;
+                    b_end = (cur_b + 1) * rpb;
                     gsum = 0.f;
+                    gt = gate ? gate[cur_b * C + c] : 1.f;
                 }
-                const float a0 = v[(r * 3 + 0) * C + c], a1 = v[(r * 3 + 1) * C + c], a2 = v[(r * 3 + 2) * C + c];
-                const float g0 = g[(r * 3 + 0) * C + c], g1 = g[(r * 3 + 1) * C + c], g2 = g[(r * 3 + 2) * C + c];
-                const float n = sqrtf(a0 * a0 + a1 * a1 + a2 * a2) + VEPS;
-                const float nh = (n - mu) * is;
-                const float rr = nh * ga + be;
-                const float gv = g0 * a0 + g1 * a1 + g2 * a2;  // sum_i g_i v_i
-                const float gt = gate ? gate[b * C + c] : 1.f;
-                gsum += gv * (rr / n);
-                const float dr = gv * gt / n;
-                acc[0] += (double)dr;
-                acc[1] += (double)dr * (double)nh;
+                // up to four rows of this cloud at a time: their 24 loads are issued before the first use
+                const int64_t lim = min(r1, b_end);
+                float a0[4], a1[4], a2[4], g0[4], g1[4], g2[4];
+                int nb = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t ru = r + (int64_t)u * RL;
+                    const bool in = ru < lim;
+                    const int64_t rc = in ? ru : r;
+                    a0[u] = v[(rc * 3 + 0) * C + c]; a1[u] = v[(rc * 3 + 1) * C + c]; a2[u] = v[(rc * 3 + 2) * C + c];
+                    g0[u] = g[(rc * 3 + 0) * C + c]; g1[u] = g[(rc * 3 + 1) * C + c]; g2[u] = g[(rc * 3 + 2) * C + c];
+                    nb += in ? 1 : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (u < nb) {
+                        const float n = sqrtf(a0[u] * a0[u] + a1[u] * a1[u] + a2[u] * a2[u]) + VEPS;
+                        const float nh = (n - mu) * is;
+                        const float rr = nh * ga + be;
+                        const float gv = g0[u] * a0[u] + g1[u] * a1[u] + g2[u] * a2[u];  // sum_i g_i v_i
+                        gsum += gv * (rr / n);
+                        const float dr = gv * gt / n;
+                        acc[0] += (double)dr;
+                        acc[1] += (double)dr * (double)nh;
+                    }
+                }
+                r += (int64_t)nb * RL;
             }
             if (cur_b >= 0 && dgate) atomicAdd(&dgate[cur_b * C + c], gsum);
         }
