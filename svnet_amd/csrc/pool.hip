@@ -47,7 +47,15 @@ __global__ __launch_bounds__(256) void pool_mean_split_kernel(const float* __res
     for (int64_t i = threadIdx.x; i < inner; i += blockDim.x) {
         const float* p = x + o * R * inner + i;
         float s = 0.f;
-        for (int64_t r = r0; r < r1; ++r) s += p[r * inner];
+        int64_t r = r0;
+        for (; r + 7 < r1; r += 8) {          // eight rows' loads in flight per thread
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = p[(r + u) * inner];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += t[u];
+        }
+        for (; r < r1; ++r) s += p[r * inner];
         atomicAdd(&out[o * inner + i], s * invR);
     }
 }
@@ -68,7 +76,16 @@ __global__ __launch_bounds__(256) void pool_max_split_kernel(const float* __rest
         const float* p = x + o * R * inner + i;
         float best = p[r0 * inner];
         int64_t bi = r0;
-        for (int64_t r = r0 + 1; r < r1; ++r) {
+        int64_t r = r0 + 1;
+        for (; r + 7 < r1; r += 8) {          // eight rows' loads in flight per thread; strict '>' keeps the first index
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = p[(r + u) * inner];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (t[u] > best) { best = t[u]; bi = r + u; }
+        }
+        for (; r < r1; ++r) {
             const float v = p[r * inner];
             if (v > best) { best = v; bi = r; }
         }
