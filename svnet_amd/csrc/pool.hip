@@ -329,8 +329,11 @@ __global__ __launch_bounds__(256) void gate_mlp_bwd_kernel(const float* __restri
                                                            const float* __restrict__ W0, const float* __restrict__ W2, int Cin, int H,
                                                            int Ov, float out_scale, float* __restrict__ dgin, float* __restrict__ dW0,
                                                            float* __restrict__ dW2) {
+    // grid (B, chunks): every workgroup recomputes the two short per-cloud vectors (cheap) and takes every chunks-th slice of
+    // the three output loops, so that a wide layer (conv5: 85 x 256 + 170 x 85 outputs) is not 32 long serial loops
     __shared__ float dgp[256], dhp[256];
     const int b = blockIdx.x, tid = threadIdx.x;
+    const int t0 = blockIdx.y * blockDim.x + tid, ts = gridDim.y * blockDim.x;
     for (int o = tid; o < Ov; o += blockDim.x) {
         const float gt = gate[(size_t)b * Ov + o];
         dgp[o] = dgate[(size_t)b * Ov + o] * gt * (1.f - gt);
@@ -338,21 +341,23 @@ __global__ __launch_bounds__(256) void gate_mlp_bwd_kernel(const float* __restri
     __syncthreads();
     for (int j = tid; j < H; j += blockDim.x) {
         float a = 0.f;
+#pragma unroll 8
         for (int o = 0; o < Ov; ++o) a = fmaf(dgp[o], W2[o * H + j], a);
         dhp[j] = h[(size_t)b * H + j] > 0.f ? a : 0.f;
     }
     __syncthreads();
-    for (int e = tid; e < Ov * H; e += blockDim.x) {
+    for (int e = t0; e < Ov * H; e += ts) {
         const int o = e / H, j = e - o * H;
         atomicAdd(&dW2[e], dgp[o] * h[(size_t)b * H + j]);
     }
-    for (int e = tid; e < H * Cin; e += blockDim.x) {
+    for (int e = t0; e < H * Cin; e += ts) {
         const int j = e / Cin, c = e - j * Cin;
         atomicAdd(&dW0[e], dhp[j] * gin[(size_t)b * Cin + c] * in_scale);
     }
     if (dgin) {
-        for (int c = tid; c < Cin; c += blockDim.x) {
+        for (int c = t0; c < Cin; c += ts) {
             float a = 0.f;
+#pragma unroll 8
             for (int j = 0; j < H; ++j) a = fmaf(dhp[j], W0[j * Cin + c], a);
             dgin[(size_t)b * Cin + c] = a * out_scale;
         }
@@ -379,8 +384,11 @@ extern "C" int svnet_gate_mlp_bwd_f32(const float* dgate, const float* gate, con
                   "svnet_gate_mlp_bwd_f32: bad arguments");
     SVNET_REQUIRE(H <= 256 && Ov <= 256, SVNET_E_UNSUPPORTED, "svnet_gate_mlp_bwd_f32: H, Ov must be <= 256");
     if (B == 0) return SVNET_OK;
-    hipLaunchKernelGGL(gate_mlp_bwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, dgate, gate, h, gin, in_scale, W0, W2,
-                       (int)Cin, (int)H, (int)Ov, out_scale, dgin, dW0, dW2);
+    int64_t chunks = svnet_cdiv(H * Cin + Ov * H, 256 * 8);          // ~8 outputs per thread
+    if (chunks > 16) chunks = 16;
+    if (chunks < 1) chunks = 1;
+    hipLaunchKernelGGL(gate_mlp_bwd_kernel, dim3((unsigned)B, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, dgate, gate, h, gin,
+                       in_scale, W0, W2, (int)Cin, (int)H, (int)Ov, out_scale, dgin, dW0, dW2);
     SVNET_CHECK_LAUNCH("gate_mlp_bwd_kernel");
     return SVNET_OK;
 }
