@@ -29,22 +29,18 @@ __global__ __launch_bounds__(256) void binweight_values_kernel(const float* __re
     }
 }
 
+// one wave per (row, word): lane b loads the weight of bit b, two ballots make the plane words
 __global__ __launch_bounds__(256) void binweight_pack_kernel(const float* __restrict__ W, int64_t O, int64_t K, int64_t KW,
                                                              uint64_t* __restrict__ w_sign, uint64_t* __restrict__ w_nz) {
+    const int lane = threadIdx.x & 63;
     const int64_t total = O * KW;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t e = wave0; e < total; e += nwaves) {
         const int64_t o = e / KW, w = e - o * KW;
-        uint64_t sg = 0, nz = 0;
-        for (int b = 0; b < 64; ++b) {
-            const int64_t k = w * 64 + b;
-            if (k < K) {
-                const float v = W[o * K + k];
-                if (v > 0.f) sg |= 1ull << b;
-                if (v != 0.f) nz |= 1ull << b;
-            }
-        }
-        w_sign[e] = sg;
-        w_nz[e] = nz;
+        const int64_t k = w * 64 + lane;
+        const float v = k < K ? W[o * K + k] : 0.f;
+        const uint64_t sg = __ballot(v > 0.f), nz = __ballot(v != 0.f);
+        if (lane == 0) { w_sign[e] = sg; w_nz[e] = nz; }
     }
 }
 
@@ -248,7 +244,7 @@ extern "C" int svnet_binweight_prepare_f32(const float* W, const float* scale, i
     }
     if (w_sign) {
         const int64_t KW = svnet_cdiv(K, 64);
-        hipLaunchKernelGGL(binweight_pack_kernel, dim3(svnet_grid(O * KW, 256)), dim3(256), 0, st, W, O, K, KW, w_sign, w_nz);
+        hipLaunchKernelGGL(binweight_pack_kernel, dim3(svnet_grid(O * KW * 64, 256)), dim3(256), 0, st, W, O, K, KW, w_sign, w_nz);
         SVNET_CHECK_LAUNCH("binweight_pack_kernel");
     }
     return SVNET_OK;

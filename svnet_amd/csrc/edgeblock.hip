@@ -37,29 +37,23 @@ __device__ __forceinline__ int fused_feature(int w, int b, int Cs, int Cv) {
     return b < 2 * Cv ? 2 * Cs + b * 3 + (w - 2) : -1;
 }
 
-__global__ void edgeblock_prepare_kernel(const float* __restrict__ W, const float* __restrict__ beta, int Os, int Cs, int Cv,
-                                         uint64_t* __restrict__ w_sign, uint64_t* __restrict__ w_nz, float* __restrict__ beta_perm) {
+// one wave per (output channel, word): lane b loads the weight of bit b, two ballots make the plane words
+__global__ __launch_bounds__(256) void edgeblock_prepare_kernel(const float* __restrict__ W, const float* __restrict__ beta, int Os, int Cs,
+                                                                int Cv, uint64_t* __restrict__ w_sign, uint64_t* __restrict__ w_nz,
+                                                                float* __restrict__ beta_perm) {
     const int K1 = 2 * Cs + 6 * Cv;
-    const int total = Os * NW;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total + NW * 64; e += gridDim.x * blockDim.x) {
-        if (e < total) {
-            const int o = e / NW, w = e - o * NW;
-            uint64_t sg = 0, nz = 0;
-            for (int b = 0; b < 64; ++b) {
-                const int f = fused_feature(w, b, Cs, Cv);
-                if (f >= 0) {
-                    const float v = W[(int64_t)o * K1 + f];
-                    if (v > 0.f) sg |= 1ull << b;
-                    if (v != 0.f) nz |= 1ull << b;
-                }
-            }
-            w_sign[e] = sg;
-            w_nz[e] = nz;
-        } else {
-            const int q = e - total, w = q / 64, b = q - w * 64;
-            const int f = fused_feature(w, b, Cs, Cv);
-            beta_perm[q] = f >= 0 ? beta[f] : 0.f;
-        }
+    const int lane = threadIdx.x & 63;
+    const int item = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);      // (o, w) pairs, then the NW beta words
+    if (item < Os * NW) {
+        const int o = item / NW, w = item - o * NW;
+        const int f = fused_feature(w, lane, Cs, Cv);
+        const float v = f >= 0 ? W[(int64_t)o * K1 + f] : 0.f;
+        const uint64_t sg = __ballot(v > 0.f), nz = __ballot(v != 0.f);
+        if (lane == 0) { w_sign[item] = sg; w_nz[item] = nz; }
+    } else if (item < Os * NW + NW) {
+        const int w = item - Os * NW;
+        const int f = fused_feature(w, lane, Cs, Cv);
+        beta_perm[w * 64 + lane] = f >= 0 ? beta[f] : 0.f;
     }
 }
 
@@ -391,7 +385,7 @@ extern "C" int svnet_edgeblock_prepare_f32(const float* W, const float* beta, in
                                            uint64_t* w_nz, float* beta_perm, void* stream) {
     SVNET_REQUIRE(W && beta && w_sign && w_nz && beta_perm, SVNET_E_ARG, "svnet_edgeblock_prepare_f32: null pointer");
     SVNET_REQUIRE(Cs > 0 && Cs <= 64 && Cv > 0 && 2 * Cv <= 64 && Os > 0, SVNET_E_UNSUPPORTED, "svnet_edgeblock_prepare_f32: needs Cs <= 64, 2*Cv <= 64");
-    hipLaunchKernelGGL(edgeblock_prepare_kernel, dim3((unsigned)svnet_cdiv(Os * NW + NW * 64, 256)), dim3(256), 0, (hipStream_t)stream, W,
+    hipLaunchKernelGGL(edgeblock_prepare_kernel, dim3((unsigned)svnet_cdiv((Os * NW + NW) * 64, 256)), dim3(256), 0, (hipStream_t)stream, W,
                        beta, (int)Os, (int)Cs, (int)Cv, w_sign, w_nz, beta_perm);
     SVNET_CHECK_LAUNCH("edgeblock_prepare_kernel");
     return SVNET_OK;
