@@ -92,16 +92,17 @@ __global__ __launch_bounds__(256) void binlinear_fwd_kernel(const float* __restr
     for (int64_t tile = blockIdx.x / o_blocks; tile < tiles; tile += gridDim.x / o_blocks) {
         const int64_t row0 = tile * ROWS;
         const int rows = (int)min((int64_t)ROWS, M - row0);
-        // ---- phase 1: binarize + pack. wave w handles rows w, w+4, ... in batches of 4 words; the next batch's loads (possibly
-        // of the next row) are issued before the current batch is balloted, so 8 loads per lane are always in flight
+        // ---- phase 1: binarize + pack. wave w handles rows w, w+4, ... in batches of PB words; the next batch's loads (possibly
+        // of the next row) are issued before the current batch is balloted, so 2*PB loads per lane are always in flight
         {
             int lr = wave, lw = 0;                                   // load cursor (row, first word of the batch)
-            float tn[4];
+            constexpr int PB = KWM >= 16 ? 16 : 4;                   // wide rows: 16-word batches (the head layers are pure latency)
+            float tn[PB];
 #define SVNET_BL_LOAD()                                                                                   \
     do {                                                                                                  \
         if (lr < rows) {                                                                                  \
             const float* xr_ = x + (row0 + lr) * ldx;                                                     \
-            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                               \
+            _Pragma("unroll") for (int u = 0; u < PB; ++u) {                                              \
                 const int k_ = (lw + u) * 64 + lane;                                                      \
                 const int kc_ = k_ < K ? k_ : K - 1; /* clamped: unconditional loads */                   \
                 tn[u] = xr_[kc_] + beta[kc_];                                                             \
@@ -111,14 +112,14 @@ __global__ __launch_bounds__(256) void binlinear_fwd_kernel(const float* __restr
             SVNET_BL_LOAD();
             int r = wave, w0 = 0;                                    // use cursor
             while (r < rows) {
-                float t[4];
+                float t[PB];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) t[u] = tn[u];
-                lw += 4;
+                for (int u = 0; u < PB; ++u) t[u] = tn[u];
+                lw += PB;
                 if (lw >= KW) { lw = 0; lr += 4; }
                 SVNET_BL_LOAD();
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < PB; ++u) {
                     const int w = w0 + u;
                     const bool in = (w * 64 + lane) < K;
                     const float tv = in ? t[u] : 0.f;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void binlinear_fwd_kernel(const float* __restr
                         lt[r * KW + w] = st;
                     }
                 }
-                w0 += 4;
+                w0 += PB;
                 if (w0 >= KW) { w0 = 0; r += 4; }
             }
 #undef SVNET_BL_LOAD
@@ -140,8 +141,8 @@ __global__ __launch_bounds__(256) void binlinear_fwd_kernel(const float* __restr
         // ---- saved planes (training), written ROW-SLICED: word [tile*K + k] = bit r of column k for the tile's
         // 64 rows (a 64x64 bit transpose per word by 64 ballots; rows beyond M contribute 0).  This is the layout
         // the backward MFMA kernels consume with one coalesced u64 per lane (gemm_mfma.hip).
-        if (x_sign && ob == 0) {
-            for (int item = wave; item < 3 * KW; item += 4) {
+        if (x_sign) {   // (the o_blocks workgroups of a small-M tile share the 3*KW transpositions)
+            for (int item = ob * 4 + wave; item < 3 * KW; item += 4 * o_blocks) {
                 const int pl = item / KW, w = item - pl * KW;
                 const uint64_t* src = (pl == 0) ? ls : ((pl == 1) ? lz : lt);
                 uint64_t* dst = (pl == 0) ? x_sign : ((pl == 1) ? x_nz : x_ste);
