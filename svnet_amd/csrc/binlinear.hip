@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void binlinear_fwd_kernel(const float* __restr
         // of the next row) are issued before the current batch is balloted, so 2*PB loads per lane are always in flight
         {
             int lr = wave, lw = 0;                                   // load cursor (row, first word of the batch)
-            constexpr int PB = KWM >= 16 ? 16 : 4;                   // wide rows: 16-word batches (the head layers are pure latency)
+            constexpr int PB = KWM >= 16 ? 16 : (KWM >= 8 ? 8 : 4);  // wide rows: whole-row batches (these passes are pure latency)
             float tn[PB];
 #define SVNET_BL_LOAD()                                                                                   \
     do {                                                                                                  \
