@@ -212,10 +212,11 @@ int svnet_knn_reverse_i32(const int64_t* idx, int64_t B, int64_t N, int64_t k, i
  * that svnet_edgeblock_bwd_f32 writes instead of scattering with float atomics.                                       */
 int64_t svnet_edgeblock_msg_stride(int64_t Cs, int64_t Cv, int64_t Ov);
 /* Sums the message rows over the reverse lists (one wave per destination point, no atomics) and finishes the point-level
- * gradients: acat [3P, 2Ov+6] = [dU | dT | dZp | dZq] (dU = sum - dvc, dT = dvc, ...), ds_acc [P,Cs] += , dv_acc [P,3,Cv] +=,
+ * gradients: acat [3P, acat_ld] = [dU | dT | dZp | dZq | pad] (dU = sum - dvc, dT = dvc, ...), ds_acc [P,Cs] += , dv_acc [P,3,Cv] +=,
  * dbeta1 [2Cs+6Cv] = dbeta_perm in the reference's feature order.                                                     */
 int svnet_edgeblock_bwd_gather_f32(const float* msg, const int32_t* rev_range, const int32_t* rev_edge, const float* dvc,
                                    const float* dzc, int64_t P, int64_t Cs, int64_t Cv, int64_t Ov, float* acat,
+                                   int64_t acat_ld /* row stride of acat, >= 2Ov+6 (a multiple of 4 keeps the GEMM's loads 16-byte) */,
                                    float* ds_acc, float* dv_acc, const float* dbeta_perm, float* dbeta1, void* stream);
 /* STE chain rule (svnet_binweight_grad_f32's formula, ASSIGNED) for linear1 from GXp [Os,320] (fused column order), for
  * linear2 from GXc[0:2Ov] and for the v2s frame from GXc[2Ov:2Ov+6]  (GXc [2Ov+6, Cv]).                              */

@@ -732,7 +732,8 @@ class EdgeBlock(torch.autograd.Function):
 
         # ---- neighbour sums -> gradient rows of the collapsed per-point products [U | T | Zp | Zq], ds, dv; dbeta in the
         # reference's feature order
-        acat = torch.empty((3 * P, R), **f32)
+        Rp = (R + 3) // 4 * 4                    # padded row stride: 16-byte fragment loads in the two GEMMs below
+        acat = torch.empty((3 * P, Rp), **f32)
         dbeta1 = torch.empty((1, K1), **f32)
         # linear1's weight-gradient product GXp = dy^T . x_b (MFMA, ternary planes, fused column order) only needs the tile
         # kernel's outputs: it keeps the main stream while the side stream (joined with main first) sums the messages
@@ -744,11 +745,11 @@ class EdgeBlock(torch.autograd.Function):
         gemm(320, Os, E, a_planes=(x_sign, x_nz), B=dn_out, b_rs=Os, b_cs=1, C=GXp, ldc=1, c_cs=320, accumulate=True,
              tern_tile_mask=used)
         with torch.cuda.stream(side):
-            call("svnet_edgeblock_bwd_gather_f32", _p(msg), _p(rev_range), _p(rev_edge), _p(dvc), _p(dzc), P, Cs, Cv, Ov, _p(acat),
+            call("svnet_edgeblock_bwd_gather_f32", _p(msg), _p(rev_range), _p(rev_edge), _p(dvc), _p(dzc), P, Cs, Cv, Ov, _p(acat), Rp,
                  _p(ds_acc), _p(dv_acc), _p(dbeta_perm), _p(dbeta1), _stream())
             # linear2 and the v2s frame: dv += (acat * scv) . wv ;  GXc = acat^T . v
-            gemm(3 * P, Cv, R, A=acat, a_rs=R, a_cs=1, a_scale=scv, B=wv, b_rs=Cv, b_cs=1, b_exact=True, C=dv_acc, ldc=Cv, accumulate=True)
-            gemm(R, Cv, 3 * P, A=acat, a_rs=1, a_cs=R, B=v, b_rs=Cv, b_cs=1, C=GXc, ldc=Cv, accumulate=True)
+            gemm(3 * P, Cv, R, A=acat, a_rs=Rp, a_cs=1, a_scale=scv, B=wv, b_rs=Cv, b_cs=1, b_exact=True, C=dv_acc, ldc=Cv, accumulate=True)
+            gemm(R, Cv, 3 * P, A=acat, a_rs=1, a_cs=Rp, B=v, b_rs=Cv, b_cs=1, C=GXc, ldc=Cv, accumulate=True)
         main.wait_stream(side)
         dW1, dW2, dWz = torch.empty((Os, K1), **f32), torch.empty((Ov, 2 * Cv), **f32), torch.empty((3, 2 * Cv), **f32)
         dsc1, dsc2, dscz = torch.empty((Os,), **f32), torch.empty((Ov,), **f32), torch.empty((3,), **f32)

@@ -131,7 +131,7 @@ template <int NCH>
 __global__ __launch_bounds__(256) void edgeblock_bwd_gather_kernel(const float* __restrict__ msg, const int32_t* __restrict__ rev_range,
                                                                    const int32_t* __restrict__ rev_edge, const float* __restrict__ dvc,
                                                                    const float* __restrict__ dzc, int64_t P, int Cs, int Cv, int Ov, int R,
-                                                                   float* __restrict__ acat, float* __restrict__ ds_acc,
+                                                                   float* __restrict__ acat, int RW, float* __restrict__ ds_acc,
                                                                    float* __restrict__ dv_acc, const float* __restrict__ dbeta_perm,
                                                                    float* __restrict__ dbeta1) {
     const int lane = threadIdx.x & 63;
@@ -181,7 +181,6 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_gather_kernel(const float* 
             for (int q = 0; q < NCH; ++q) acc[q] += cur[q];
         }
     }
-    const int RW = 2 * Ov + 6;
     const int oV = Cs, oZ = oV + 3 * Cv, oU = oZ + 9;                 // msg row = [ds (Cs) | dve (3 Cv) | dz (9) | dv' (3 Ov) | pad]
 #pragma unroll
     for (int q = 0; q < NCH; ++q) {
@@ -246,7 +245,9 @@ extern "C" int svnet_knn_reverse_i32(const int64_t* idx, int64_t B, int64_t N, i
 
 extern "C" int svnet_edgeblock_bwd_gather_f32(const float* msg, const int32_t* rev_range, const int32_t* rev_edge, const float* dvc,
                                               const float* dzc, int64_t P, int64_t Cs, int64_t Cv, int64_t Ov, float* acat,
-                                              float* ds_acc, float* dv_acc, const float* dbeta_perm, float* dbeta1, void* stream) {
+                                              int64_t acat_ld, float* ds_acc, float* dv_acc, const float* dbeta_perm, float* dbeta1,
+                                              void* stream) {
+    SVNET_REQUIRE(acat_ld >= 2 * Ov + 6, SVNET_E_ARG, "svnet_edgeblock_bwd_gather_f32: acat_ld < 2*Ov + 6");
     SVNET_REQUIRE(msg && rev_range && rev_edge && dvc && dzc && acat && ds_acc && dv_acc && dbeta_perm && dbeta1 && P > 0, SVNET_E_ARG,
                   "svnet_edgeblock_bwd_gather_f32: bad arguments");
     SVNET_REQUIRE(Cs > 0 && Cs <= 64 && Cv > 0 && 2 * Cv <= 64 && Ov > 0 && Ov <= 64, SVNET_E_UNSUPPORTED,
@@ -257,7 +258,7 @@ extern "C" int svnet_edgeblock_bwd_gather_f32(const float* msg, const int32_t* r
     hipStream_t st = (hipStream_t)stream;
 #define SVNET_GATHER(NCH)                                                                                                         \
     hipLaunchKernelGGL((edgeblock_bwd_gather_kernel<NCH>), dim3(grid), dim3(256), 0, st, msg, rev_range, rev_edge, dvc, dzc, P, (int)Cs, \
-                       (int)Cv, (int)Ov, R, acat, ds_acc, dv_acc, dbeta_perm, dbeta1)
+                       (int)Cv, (int)Ov, R, acat, (int)acat_ld, ds_acc, dv_acc, dbeta_perm, dbeta1)
     switch (nch) {
         case 1: SVNET_GATHER(1); break;
         case 2: SVNET_GATHER(2); break;
