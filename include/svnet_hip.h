@@ -186,6 +186,7 @@ typedef struct svnet_edgeblock_bwd_desc {
     const float* gconst;         /* [B,2Cs]: dL/d(gate input) / (N*k) */
     float* dn_out; uint32_t* x_sign32; uint32_t* x_nz32;
     float* msg;                  /* [E, svnet_edgeblock_msg_stride]: per-edge neighbour contributions (written, not accumulated) */
+    float* ub_tab; float* ge_tab; /* [P,3,Ov] each: T_i - U_i and gv_i*gate/k, written by the vector path for the gather kernel */
     float* ds_acc; float* dv_acc; float* dvc; float* dzc; float* dbeta_perm;   /* centre sums (atomics) / dvc written */
     int64_t* debug;              /* optional [4]: {count, first bad edge, its idx value, N}; edges with idx outside [0,N) are skipped */
     int parts;                   /* 0 or 3: both kernels; 1: vector path only (the dL/dv' columns of msg, dvc); 2: scalar/tile path only.  The two
@@ -205,16 +206,20 @@ int svnet_edgeblock_bwd_coeffs_f32(const float* red, const float* redv, const fl
                                    float* bcoef, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, void* stream);
 int svnet_edgeblock_bwd_f32(const svnet_edgeblock_bwd_desc* desc, void* stream);
 /* Reverse neighbour lists of a kNN graph (idx [B*N,k], cloud-local ids): the edges e = i*k + t that point at j are
- * rev_edge[rev_range[2j] .. rev_range[2j+1]).  rev_range [2*B*N], rev_edge [B*N*k]; N <= 8192; ids outside [0,N) are skipped. */
+ * rev_edge[rev_range[2j] .. rev_range[2j+1]), their source points i (global ids) rev_src[..].  rev_range [2*B*N], rev_edge and
+ * rev_src [B*N*k]; N <= 8192; ids outside [0,N) are skipped.                                                            */
 int svnet_knn_reverse_i32(const int64_t* idx, int64_t B, int64_t N, int64_t k, int32_t* rev_range, int32_t* rev_edge,
-                          void* stream);
-/* Row stride (floats) of the per-edge message rows msg[e] = [dL/ds_j (Cs) | dL/dv_j (3*Cv) | dL/dz (9) | dL/dv' (3*Ov) | pad]
+                          int32_t* rev_src, void* stream);
+/* Row stride (floats) of the per-edge message rows msg[e] = [dL/ds_j (Cs) | dL/dv_j (3*Cv) | dL/dz (9) | pad]
  * that svnet_edgeblock_bwd_f32 writes instead of scattering with float atomics.                                       */
 int64_t svnet_edgeblock_msg_stride(int64_t Cs, int64_t Cv, int64_t Ov);
-/* Sums the message rows over the reverse lists (one wave per destination point, no atomics) and finishes the point-level
- * gradients: acat [3P, acat_ld] = [dU | dT | dZp | dZq | pad] (dU = sum - dvc, dT = dvc, ...), ds_acc [P,Cs] += , dv_acc [P,3,Cv] +=,
- * dbeta1 [2Cs+6Cv] = dbeta_perm in the reference's feature order.                                                     */
-int svnet_edgeblock_bwd_gather_f32(const float* msg, const int32_t* rev_range, const int32_t* rev_edge, const float* dvc,
+/* Sums the message rows over the reverse lists (one wave per destination point, no atomics), recomputes the neighbour's share
+ * of dL/dv' of every incoming edge from ut (U_j), ub_tab / ge_tab (source point) and the coefficients, and finishes the
+ * point-level gradients: acat [3P, acat_ld] = [dU | dT | dZp | dZq | pad] (dU = sum - dvc, dT = dvc, ...), ds_acc [P,Cs] +=,
+ * dv_acc [P,3,Cv] +=, dbeta1 [2Cs+6Cv] = dbeta_perm in the reference's feature order.                                  */
+int svnet_edgeblock_bwd_gather_f32(const float* msg, const int32_t* rev_range, const int32_t* rev_edge, const int32_t* rev_src,
+                                   const float* ut, const float* ub_tab, const float* ge_tab, const float* coef, const float* bcoef,
+                                   int64_t Os, const float* dvc,
                                    const float* dzc, int64_t P, int64_t Cs, int64_t Cv, int64_t Ov, float* acat,
                                    int64_t acat_ld /* row stride of acat, >= 2Ov+6 (a multiple of 4 keeps the GEMM's loads 16-byte) */,
                                    float* ds_acc, float* dv_acc, const float* dbeta_perm, float* dbeta1, void* stream);

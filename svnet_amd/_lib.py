@@ -69,6 +69,7 @@ class EdgeBlockBwdDesc(ctypes.Structure):
         ("coef", c_p), ("gate", c_p), ("gy", c_p), ("bcoef", c_p), ("gv", c_p), ("gconst", c_p),
         ("dn_out", c_p), ("x_sign32", c_p), ("x_nz32", c_p),
         ("msg", c_p),
+        ("ub_tab", c_p), ("ge_tab", c_p),
         ("ds_acc", c_p), ("dv_acc", c_p), ("dvc", c_p), ("dzc", c_p), ("dbeta_perm", c_p),
         ("debug", c_p),
         ("parts", c_int),
@@ -116,9 +117,9 @@ SIGNATURES = {
     "svnet_binlinear_fwd_f32": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),
     "svnet_binweight_grad_f32": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_int, c_p]),
     "svnet_edgeblock_prepare_vec_f32": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p]),
-    "svnet_knn_reverse_i32": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
+    "svnet_knn_reverse_i32": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p]),
     "svnet_edgeblock_msg_stride": (c_i64, [c_i64, c_i64, c_i64]),
-    "svnet_edgeblock_bwd_gather_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p, c_p]),
+    "svnet_edgeblock_bwd_gather_f32": (c_int, [c_p] * 9 + [c_i64] + [c_p, c_p] + [c_i64] * 4 + [c_p, c_i64, c_p, c_p, c_p, c_p, c_p]),
     "svnet_edgeblock_bwd_params_f32": (c_int, [c_p] * 8 + [c_i64] * 4 + [c_p] * 6 + [c_p]),
     "svnet_edgeblock_prepare_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p]),
     "svnet_edgeblock_fwd_f32": (c_int, [ctypes.POINTER(EdgeBlockDesc), c_p]),

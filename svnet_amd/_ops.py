@@ -681,9 +681,10 @@ class EdgeBlock(torch.autograd.Function):
         main, side = torch.cuda.current_stream(dev), _side_stream(dev)
         rev_range = torch.empty((2 * P,), dtype=torch.int32, device=dev)
         rev_edge = torch.empty((E,), dtype=torch.int32, device=dev)
+        rev_src = torch.empty((E,), dtype=torch.int32, device=dev)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            call("svnet_knn_reverse_i32", _p(idx), B, N, k, _p(rev_range), _p(rev_edge), _stream())
+            call("svnet_knn_reverse_i32", _p(idx), B, N, k, _p(rev_range), _p(rev_edge), _p(rev_src), _stream())
 
         # ---- point-level prelude: BatchNorm reductions, gate gradient
         gy = torch.empty((P, Os), **f32)
@@ -719,6 +720,8 @@ class EdgeBlock(torch.autograd.Function):
         # float atomics are executed at the memory side on this part and were the bottleneck of the scatter formulation
         msg = torch.empty((E, _lib.lib().svnet_edgeblock_msg_stride(Cs, Cv, Ov)), **f32)
         dvc = torch.empty((P, 3, Ov), **f32)
+        ub_tab, ge_tab = torch.empty((P, 3, Ov), **f32), torch.empty((P, 3, Ov), **f32)
+        d.ub_tab, d.ge_tab = _p(ub_tab), _p(ge_tab)
         d.msg, d.ds_acc, d.dv_acc, d.dvc, d.dzc, d.dbeta_perm = _p(msg), _p(ds_acc), _p(dv_acc), _p(dvc), _p(dzc), _p(dbeta_perm)
         d.debug = _p(DEBUG_BUFFER)
         # the vector path (wave per point) and the scalar path (32-edge tiles) are independent: two streams, so that the
@@ -745,8 +748,9 @@ class EdgeBlock(torch.autograd.Function):
         gemm(320, Os, E, a_planes=(x_sign, x_nz), B=dn_out, b_rs=Os, b_cs=1, C=GXp, ldc=1, c_cs=320, accumulate=True,
              tern_tile_mask=used)
         with torch.cuda.stream(side):
-            call("svnet_edgeblock_bwd_gather_f32", _p(msg), _p(rev_range), _p(rev_edge), _p(dvc), _p(dzc), P, Cs, Cv, Ov, _p(acat), Rp,
-                 _p(ds_acc), _p(dv_acc), _p(dbeta_perm), _p(dbeta1), _stream())
+            call("svnet_edgeblock_bwd_gather_f32", _p(msg), _p(rev_range), _p(rev_edge), _p(rev_src), _p(ut), _p(ub_tab), _p(ge_tab),
+                 _p(coef), _p(bcoef), Os, _p(dvc), _p(dzc), P, Cs, Cv, Ov, _p(acat), Rp, _p(ds_acc), _p(dv_acc), _p(dbeta_perm),
+                 _p(dbeta1), _stream())
             # linear2 and the v2s frame: dv += (acat * scv) . wv ;  GXc = acat^T . v
             gemm(3 * P, Cv, R, A=acat, a_rs=Rp, a_cs=1, a_scale=scv, B=wv, b_rs=Cv, b_cs=1, b_exact=True, C=dv_acc, ldc=Cv, accumulate=True)
             gemm(R, Cv, 3 * P, A=acat, a_rs=1, a_cs=Rp, B=v, b_rs=Cv, b_cs=1, C=GXc, ldc=Cv, accumulate=True)

@@ -191,11 +191,11 @@ __global__ void edgeblock_bwd_coeffs_kernel(const float* __restrict__ red, const
     }
 }
 
-__device__ __forceinline__ int msg_stride(int Cs, int Cv, int Ov) { return ((3 * Ov + Cs + 3 * Cv + 9) + 3) / 4 * 4; }   // = svnet_edgeblock_msg_stride
+__device__ __forceinline__ int msg_stride(int Cs, int Cv, int Ov) { (void)Ov; return ((Cs + 3 * Cv + 9) + 3) / 4 * 4; }   // = svnet_edgeblock_msg_stride
 
 // ---------------------------------------------------------------------------------------------- vector path
 // dL/dv' of every edge (v' = U_j - U_i + T_i, out = gate * mean_k v'*(Av + Bv/n'), n' = |v'| + eps):
-//   msg[e][Cs+3Cv+9 : +3Ov] = dv' (the neighbour's share, summed over the reverse lists by the gather kernel),
+//   ub_tab / ge_tab [P,3,Ov] = T_i - U_i and gv_i*gate/k (the gather kernel recomputes the neighbour's share of dv' from them),
 //   dvc[i] = sum_k dv' (plain store: one wave owns a point).
 // Wave per point like the forward; lanes = (edge slot g, channel c) with G = 64/Ov edges per wave-instruction.
 struct VecArgs {
@@ -220,7 +220,6 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_vec_kernel(VecArgs va) {
     const int Os = d.Os, Ov = d.Ov, k = (int)d.k;
     const int G = 64 / Ov, g = lane / Ov, c = lane - g * Ov;
     const bool act = g < G;
-    const int64_t R = msg_stride(d.Cs, d.Cv, Ov);
     const float* Av = d.coef + 4 * Os; const float* Bv = Av + Ov;
     const float* C0 = d.bcoef + 3 * Os; const float* C1 = C0 + Ov;
     const float avc = Av[c], bvc = Bv[c], c0 = C0[c], c1 = C1[c];
@@ -239,6 +238,10 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_vec_kernel(VecArgs va) {
         const float ub1 = ui[1 * 2 * Ov + Ov + c] - ui[1 * 2 * Ov + c];
         const float ub2 = ui[2 * 2 * Ov + Ov + c] - ui[2 * 2 * Ov + c];
         const float ge0 = d.gv[(gp * 3 + 0) * Ov + c] * gtk, ge1 = d.gv[(gp * 3 + 1) * Ov + c] * gtk, ge2 = d.gv[(gp * 3 + 2) * Ov + c] * gtk;
+        if (lane < Ov) {   // per-point operands of dv', kept for the gather kernel (which visits this point from its neighbours' side)
+            d.ub_tab[(gp * 3 + 0) * Ov + lane] = ub0; d.ub_tab[(gp * 3 + 1) * Ov + lane] = ub1; d.ub_tab[(gp * 3 + 2) * Ov + lane] = ub2;
+            d.ge_tab[(gp * 3 + 0) * Ov + lane] = ge0; d.ge_tab[(gp * 3 + 1) * Ov + lane] = ge1; d.ge_tab[(gp * 3 + 2) * Ov + lane] = ge2;
+        }
         float cv0 = 0.f, cv1 = 0.f, cv2 = 0.f;
         // neighbour rows one iteration ahead
         int64_t n_gj; bool n_ok; float n_u0, n_u1, n_u2;
@@ -274,11 +277,7 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_vec_kernel(VecArgs va) {
             const float dnn = -gdot * bvc * rn * rn + c0 + c1 * nn;
             const float kk = nv > 0.f ? dnn * fast_rcp(nv) : 0.f;
             const float d0 = ge0 * q + kk * vp0, d1 = ge1 * q + kk * vp1, d2 = ge2 * q + kk * vp2;
-            if (ok) {   // the neighbour's share goes into the edge's message row (summed over the reverse lists later)
-                float* m = d.msg + (gp * k + t0 + g) * R + (d.Cs + 3 * d.Cv + 9);
-                m[c] = d0; m[Ov + c] = d1; m[2 * Ov + c] = d2;
-                cv0 += d0; cv1 += d1; cv2 += d2;
-            }
+            if (ok) { cv0 += d0; cv1 += d1; cv2 += d2; }   // (the neighbour's share of dv' is recomputed by the gather kernel from the tables)
         }
 #undef SVNET_LOAD_U
         for (int gg = 1; gg < G; ++gg) {   // fold the edge slots: lanes g*Ov + c -> lane c
@@ -776,7 +775,7 @@ extern "C" int svnet_edgeblock_bwd_f32(const svnet_edgeblock_bwd_desc* desc, voi
     const svnet_edgeblock_bwd_desc& d = *desc;
     SVNET_REQUIRE(d.v && d.idx && d.zz && d.ut && d.n16 && d.planes && d.w1bt && d.scale1 && d.slot_max && d.slot_min && d.coef &&
                       d.gate && d.gy && d.bcoef && d.gv && d.gconst && d.dn_out && d.x_sign32 && d.x_nz32 && d.ds_acc && d.dv_acc &&
-                      d.msg && d.dvc && d.dzc && d.dbeta_perm,
+                      d.msg && d.dvc && d.dzc && d.dbeta_perm && d.ub_tab && d.ge_tab,
                   SVNET_E_ARG, "svnet_edgeblock_bwd_f32: null pointer");
     SVNET_REQUIRE(d.B >= 0 && d.N > 0 && d.k > 0 && d.k <= 64, SVNET_E_ARG, "svnet_edgeblock_bwd_f32: bad sizes (k <= 64)");
     SVNET_REQUIRE((d.Os & (d.Os - 1)) == 0, SVNET_E_UNSUPPORTED, "svnet_edgeblock_bwd_f32: Os must be a power of two (8..128)");

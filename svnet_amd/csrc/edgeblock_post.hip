@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void bwd_params_kernel(const float* __restrict
 // LDS (N <= 8192).  The order inside a list follows the LDS atomics and is not fixed from run to run.
 constexpr int REV_MAX_N = 8192;
 __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int64_t* __restrict__ idx, int N, int k, int32_t* __restrict__ rev_range,
-                                                          int32_t* __restrict__ rev_edge) {
+                                                          int32_t* __restrict__ rev_edge, int32_t* __restrict__ rev_src) {
     extern __shared__ int cnt[];          // [N] counts -> cursors; [N .. N+1024) scan scratch
     int* part = cnt + N;
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
@@ -119,17 +119,24 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int64_t* __rest
         if ((uint64_t)j < (uint64_t)N) {
             const int pos = atomicAdd(&cnt[(int)j], 1);
             rev_edge[e0 + pos] = (int32_t)(e0 + e);
+            rev_src[e0 + pos] = b * N + e / k;                 // global id of the edge's source point
         }
     }
 }
 
-// ---- neighbour sums of the per-edge message rows msg[e] = [ds (Cs) | dve (3 Cv) | dz (9) | dv' (3 Ov)] over the reverse
-// lists: one wave per destination point, lanes = columns (NCH chunks of 64), the next row is loaded before the current
-// one is added.  Writes the gradient rows of the collapsed products directly:
+// ---- neighbour sums over the reverse lists: one wave per destination point j, lanes = columns.
+//   message rows msg[e] = [ds (Cs) | dve (3 Cv) | dz (9)] are summed (NCH chunks of 64 columns);
+//   the neighbour's share of dL/dv' (v' = U_j - U_i + T_i) of every incoming edge is RECOMPUTED from U_j (own row) and the
+//   source point's tables ub = T_i - U_i, ge = gv_i*gate/k (lanes = Ov channels, three axes per lane): it costs ~40 VALU per
+//   edge on a kernel that waits on HBM, and saves writing and re-reading 3*Ov floats per edge.
+// Next row / next tables are requested two entries ahead.  Writes the gradient rows of the collapsed products directly:
 //   acat[(j,a), :] = [U_a - dvc | dvc | Z_a - dzc | dzc],   ds_acc[j] += S,   dv_acc[j] += V.
 template <int NCH>
 __global__ __launch_bounds__(256) void edgeblock_bwd_gather_kernel(const float* __restrict__ msg, const int32_t* __restrict__ rev_range,
-                                                                   const int32_t* __restrict__ rev_edge, const float* __restrict__ dvc,
+                                                                   const int32_t* __restrict__ rev_edge, const int32_t* __restrict__ rev_src,
+                                                                   const float* __restrict__ ut, const float* __restrict__ ub_tab,
+                                                                   const float* __restrict__ ge_tab, const float* __restrict__ coef,
+                                                                   const float* __restrict__ bcoef, int Os, const float* __restrict__ dvc,
                                                                    const float* __restrict__ dzc, int64_t P, int Cs, int Cv, int Ov, int R,
                                                                    float* __restrict__ acat, int RW, float* __restrict__ ds_acc,
                                                                    float* __restrict__ dv_acc, const float* __restrict__ dbeta_perm,
@@ -152,55 +159,76 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_gather_kernel(const float* 
     int col[NCH];
 #pragma unroll
     for (int q = 0; q < NCH; ++q) col[q] = min(64 * q + lane, R - 1);     // clamped: lanes past the row re-read its last column
-    // the list's edge ids come in with one coalesced load per 64 entries (lane n holds entry n, handed to the scalar unit by
-    // v_readlane), so a row's loads never wait on a load of their own index; rows are requested two entries ahead
+    // vector path operands of this lane's channel
+    const int o = min(lane, Ov - 1);
+    const float* Av = coef + 4 * Os; const float* C0 = bcoef + 3 * Os;
+    const float avc = Av[o], bvc = Av[Ov + o], c0 = C0[o], c1 = C0[Ov + o];
+    const float uj0 = ut[(j * 3 + 0) * 2 * Ov + o], uj1 = ut[(j * 3 + 1) * 2 * Ov + o], uj2 = ut[(j * 3 + 2) * 2 * Ov + o];
+    float ua0 = 0.f, ua1 = 0.f, ua2 = 0.f;
+    float tb[6], t2[6];
+#define SVNET_GATHER_LOAD(N_, ROWV, TABV)                                                               \
+    do {                                                                                                \
+        const float* row_ = msg + (int64_t)__builtin_amdgcn_readlane(ev, (N_)) * R;                     \
+        _Pragma("unroll") for (int q = 0; q < NCH; ++q) ROWV[q] = row_[col[q]];                         \
+        const int64_t si_ = (int64_t)__builtin_amdgcn_readlane(sv, (N_)) * 3 * Ov + o;                  \
+        TABV[0] = ub_tab[si_]; TABV[1] = ub_tab[si_ + Ov]; TABV[2] = ub_tab[si_ + 2 * Ov];              \
+        TABV[3] = ge_tab[si_]; TABV[4] = ge_tab[si_ + Ov]; TABV[5] = ge_tab[si_ + 2 * Ov];              \
+    } while (0)
+    // the list's edge ids / source points come in with one coalesced load each per 64 entries (lane n holds entry n, handed to
+    // the scalar unit by v_readlane), so a row's loads never wait on a load of their own index
     for (int base = beg; base < end; base += 64) {
         const int cnt = min(64, end - base);
         const int ev = rev_edge[base + min(lane, cnt - 1)];
+        const int sv = rev_src[base + min(lane, cnt - 1)];
         float n2[NCH];
-        {
-            const float* row = msg + (int64_t)__builtin_amdgcn_readlane(ev, 0) * R;
-#pragma unroll
-            for (int q = 0; q < NCH; ++q) nx[q] = row[col[q]];
-        }
-        if (cnt > 1) {
-            const float* row = msg + (int64_t)__builtin_amdgcn_readlane(ev, 1) * R;
-#pragma unroll
-            for (int q = 0; q < NCH; ++q) n2[q] = row[col[q]];
-        }
+        SVNET_GATHER_LOAD(0, nx, tb);
+        if (cnt > 1) SVNET_GATHER_LOAD(1, n2, t2);
         for (int n = 0; n < cnt; ++n) {
-            float cur[NCH];
+            float cur[NCH], tc[6];
 #pragma unroll
             for (int q = 0; q < NCH; ++q) { cur[q] = nx[q]; nx[q] = n2[q]; }
-            if (n + 2 < cnt) {
-                const float* row = msg + (int64_t)__builtin_amdgcn_readlane(ev, n + 2) * R;
 #pragma unroll
-                for (int q = 0; q < NCH; ++q) n2[q] = row[col[q]];
-            }
+            for (int q = 0; q < 6; ++q) { tc[q] = tb[q]; tb[q] = t2[q]; }
+            if (n + 2 < cnt) SVNET_GATHER_LOAD(n + 2, n2, t2);
 #pragma unroll
             for (int q = 0; q < NCH; ++q) acc[q] += cur[q];
+            // dv' of the edge (source i -> this point): same arithmetic as edgeblock_bwd_vec_kernel
+            const float vp0 = uj0 + tc[0], vp1 = uj1 + tc[1], vp2 = uj2 + tc[2];
+            const float nv = fast_sqrt(vp0 * vp0 + vp1 * vp1 + vp2 * vp2);
+            const float nn = nv + 1e-6f;
+            const float rn = fast_rcp(nn);
+            const float qq = avc + bvc * rn;
+            const float gdot = tc[3] * vp0 + tc[4] * vp1 + tc[5] * vp2;
+            const float dnn = -gdot * bvc * rn * rn + c0 + c1 * nn;
+            const float kk = nv > 0.f ? dnn * fast_rcp(nv) : 0.f;
+            ua0 += tc[3] * qq + kk * vp0; ua1 += tc[4] * qq + kk * vp1; ua2 += tc[5] * qq + kk * vp2;
         }
     }
-    const int oV = Cs, oZ = oV + 3 * Cv, oU = oZ + 9;                 // msg row = [ds (Cs) | dve (3 Cv) | dz (9) | dv' (3 Ov) | pad]
+#undef SVNET_GATHER_LOAD
+    const int oV = Cs, oZ = oV + 3 * Cv;                               // msg row = [ds (Cs) | dve (3 Cv) | dz (9) | pad]
 #pragma unroll
     for (int q = 0; q < NCH; ++q) {
         const int c = 64 * q + lane;
-        if (c >= oU + 3 * Ov) continue;
+        if (c >= oZ + 9) continue;
         const float v = acc[q];
         if (c < oV) {
             ds_acc[j * Cs + c] += v;
         } else if (c < oZ) {
             dv_acc[j * 3 * Cv + (c - oV)] += v;
-        } else if (c < oU) {
+        } else {
             const int z = c - oZ, a = z / 3, jz = z - a * 3;
             const float cen = dzc[j * 9 + z];
             acat[(j * 3 + a) * RW + 2 * Ov + jz] = v - cen;
             acat[(j * 3 + a) * RW + 2 * Ov + 3 + jz] = cen;
-        } else {
-            const int u = c - oU, a = u / Ov, o = u - a * Ov;
-            const float cen = dvc[(j * 3 + a) * Ov + o];
-            acat[(j * 3 + a) * RW + o] = v - cen;
-            acat[(j * 3 + a) * RW + Ov + o] = cen;
+        }
+    }
+    if (lane < Ov) {
+        const float ua[3] = {ua0, ua1, ua2};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float cen = dvc[(j * 3 + a) * Ov + lane];
+            acat[(j * 3 + a) * RW + lane] = ua[a] - cen;
+            acat[(j * 3 + a) * RW + Ov + lane] = cen;
         }
     }
 }
@@ -232,44 +260,43 @@ extern "C" int svnet_edgeblock_bwd_params_f32(const float* GXp, const float* GXc
 }
 
 extern "C" int svnet_knn_reverse_i32(const int64_t* idx, int64_t B, int64_t N, int64_t k, int32_t* rev_range, int32_t* rev_edge,
-                                     void* stream) {
-    SVNET_REQUIRE(idx && rev_range && rev_edge && B >= 0 && N > 0 && k > 0, SVNET_E_ARG, "svnet_knn_reverse_i32: bad arguments");
+                                     int32_t* rev_src, void* stream) {
+    SVNET_REQUIRE(idx && rev_range && rev_edge && rev_src && B >= 0 && N > 0 && k > 0, SVNET_E_ARG, "svnet_knn_reverse_i32: bad arguments");
     SVNET_REQUIRE(N <= REV_MAX_N, SVNET_E_UNSUPPORTED, "svnet_knn_reverse_i32: N=%lld > %d", (long long)N, REV_MAX_N);
     SVNET_REQUIRE(B * N * k < (int64_t)1 << 31, SVNET_E_UNSUPPORTED, "svnet_knn_reverse_i32: more than 2^31 edges");
     if (B == 0) return SVNET_OK;
     hipLaunchKernelGGL(knn_reverse_kernel, dim3((unsigned)B), dim3(1024), (size_t)(N + 1024) * sizeof(int), (hipStream_t)stream, idx, (int)N,
-                       (int)k, rev_range, rev_edge);
+                       (int)k, rev_range, rev_edge, rev_src);
     SVNET_CHECK_LAUNCH("knn_reverse_kernel");
     return SVNET_OK;
 }
 
-extern "C" int svnet_edgeblock_bwd_gather_f32(const float* msg, const int32_t* rev_range, const int32_t* rev_edge, const float* dvc,
-                                              const float* dzc, int64_t P, int64_t Cs, int64_t Cv, int64_t Ov, float* acat,
-                                              int64_t acat_ld, float* ds_acc, float* dv_acc, const float* dbeta_perm, float* dbeta1,
-                                              void* stream) {
+extern "C" int svnet_edgeblock_bwd_gather_f32(const float* msg, const int32_t* rev_range, const int32_t* rev_edge, const int32_t* rev_src,
+                                              const float* ut, const float* ub_tab, const float* ge_tab, const float* coef,
+                                              const float* bcoef, int64_t Os, const float* dvc, const float* dzc, int64_t P, int64_t Cs,
+                                              int64_t Cv, int64_t Ov, float* acat, int64_t acat_ld, float* ds_acc, float* dv_acc,
+                                              const float* dbeta_perm, float* dbeta1, void* stream) {
+    SVNET_REQUIRE(msg && rev_range && rev_edge && rev_src && ut && ub_tab && ge_tab && coef && bcoef && dvc && dzc && acat && ds_acc &&
+                      dv_acc && dbeta_perm && dbeta1 && P > 0 && Os > 0, SVNET_E_ARG, "svnet_edgeblock_bwd_gather_f32: bad arguments");
     SVNET_REQUIRE(acat_ld >= 2 * Ov + 6, SVNET_E_ARG, "svnet_edgeblock_bwd_gather_f32: acat_ld < 2*Ov + 6");
-    SVNET_REQUIRE(msg && rev_range && rev_edge && dvc && dzc && acat && ds_acc && dv_acc && dbeta_perm && dbeta1 && P > 0, SVNET_E_ARG,
-                  "svnet_edgeblock_bwd_gather_f32: bad arguments");
     SVNET_REQUIRE(Cs > 0 && Cs <= 64 && Cv > 0 && 2 * Cv <= 64 && Ov > 0 && Ov <= 64, SVNET_E_UNSUPPORTED,
                   "svnet_edgeblock_bwd_gather_f32: needs Cs <= 64, 2*Cv <= 64, Ov <= 64");
     const int R = (int)svnet_edgeblock_msg_stride(Cs, Cv, Ov);
     const int nch = (R + 63) / 64;
     const unsigned grid = (unsigned)svnet_cdiv(P, 4);
     hipStream_t st = (hipStream_t)stream;
-#define SVNET_GATHER(NCH)                                                                                                         \
-    hipLaunchKernelGGL((edgeblock_bwd_gather_kernel<NCH>), dim3(grid), dim3(256), 0, st, msg, rev_range, rev_edge, dvc, dzc, P, (int)Cs, \
-                       (int)Cv, (int)Ov, R, acat, (int)acat_ld, ds_acc, dv_acc, dbeta_perm, dbeta1)
+#define SVNET_GATHER(NCH)                                                                                                            \
+    hipLaunchKernelGGL((edgeblock_bwd_gather_kernel<NCH>), dim3(grid), dim3(256), 0, st, msg, rev_range, rev_edge, rev_src, ut, ub_tab, \
+                       ge_tab, coef, bcoef, (int)Os, dvc, dzc, P, (int)Cs, (int)Cv, (int)Ov, R, acat, (int)acat_ld, ds_acc, dv_acc,   \
+                       dbeta_perm, dbeta1)
     switch (nch) {
         case 1: SVNET_GATHER(1); break;
         case 2: SVNET_GATHER(2); break;
-        case 3: SVNET_GATHER(3); break;
-        case 4: SVNET_GATHER(4); break;
-        case 5: SVNET_GATHER(5); break;
-        default: SVNET_GATHER(6); break;
+        default: SVNET_GATHER(3); break;
     }
 #undef SVNET_GATHER
     SVNET_CHECK_LAUNCH("edgeblock_bwd_gather_kernel");
     return SVNET_OK;
 }
 
-extern "C" int64_t svnet_edgeblock_msg_stride(int64_t Cs, int64_t Cv, int64_t Ov) { return ((3 * Ov + Cs + 3 * Cv + 9) + 3) / 4 * 4; }
+extern "C" int64_t svnet_edgeblock_msg_stride(int64_t Cs, int64_t Cv, int64_t Ov) { (void)Ov; return ((Cs + 3 * Cv + 9) + 3) / 4 * 4; }

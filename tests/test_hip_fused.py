@@ -169,8 +169,9 @@ def test_knn_reverse_lists_are_a_permutation_of_the_edges(hip_device):
     P, E = B * N, B * N * k
     rng = torch.empty(2 * P, dtype=torch.int32, device=hip_device)
     red = torch.full((E,), -7, dtype=torch.int32, device=hip_device)
-    call("svnet_knn_reverse_i32", _p(d_idx), B, N, k, _p(rng), _p(red), _stream())
-    rng, red = rng.cpu().numpy().reshape(P, 2), red.cpu().numpy()
+    src = torch.full((E,), -7, dtype=torch.int32, device=hip_device)
+    call("svnet_knn_reverse_i32", _p(d_idx), B, N, k, _p(rng), _p(red), _p(src), _stream())
+    rng, red, src = rng.cpu().numpy().reshape(P, 2), red.cpu().numpy(), src.cpu().numpy()
     flat = idx.reshape(-1).numpy()
     seen = np.zeros(E, dtype=np.int64)
     for j in range(P):
@@ -179,6 +180,7 @@ def test_knn_reverse_lists_are_a_permutation_of_the_edges(hip_device):
             assert 0 <= e < E and e // (N * k) == b            # an edge of the same cloud ...
             assert flat[e] == j - b * N                         # ... that points at j
             seen[e] += 1
+        assert np.array_equal(src[rng[j, 0]:rng[j, 1]], red[rng[j, 0]:rng[j, 1]] // k)   # source point of every listed edge
     valid = (flat >= 0) & (flat < N)
     assert np.array_equal(seen, valid.astype(np.int64))
 
