@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void mfma_tn_tern_kernel(TnArgs a) {
         }
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // row ranges stay in SGPRs
     const int r = lane & 31, h = lane >> 5;
     const int ptw = a.ptiles_per_block;                      // 1, 2 or 4
     const int p0 = (blockIdx.y * ptw + (wave % ptw)) * 32;
@@ -384,23 +384,41 @@ __global__ __launch_bounds__(256, 2) void mfma_tn_tern_kernel(TnArgs a) {
     if (live && mb < me) {
         const int64_t mlast = a.M - 1;
         uint64_t wsg[NQ], wnz[NQ], nsg[NQ], nnz[NQ];
-        float xn[8];
+        uint64_t slot_live[NQ];          // all ones when slot t holds a tile that exists and is in use (wave-uniform)
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) {
+            const int qt = SVNET_QT(t);
+            slot_live[t] = (qt >= 0 && qt * 32 < a.Q && ((a.qmask >> qt) & 1u)) ? ~0ull : 0ull;
+        }
+        int qcol[NQ];
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) qcol[t] = min(max(SVNET_QT(t), 0) * 32 + r, a.Q - 1);
+        const int lane_off = 8 * h * (int)a.lda + p;
+        constexpr int NPF = NQ <= 5 ? 4 : 1;   // k-steps of A in flight (8 loads each): a whole 64-row block ahead when the registers allow
+        float xn[NPF * 8];
 #define SVNET_TN_WORDS(M64, SG, NZ)                                                      \
     do {                                                                                 \
+        const uint64_t* sg_ = a.b_sign + ((M64) >> 6) * a.Q;                             \
+        const uint64_t* nz_ = a.b_nz + ((M64) >> 6) * a.Q;                               \
         _Pragma("unroll") for (int t = 0; t < NQ; ++t) {                                 \
-            const int q_ = min(max(SVNET_QT(t), 0) * 32 + r, a.Q - 1);                   \
-            SG[t] = a.b_sign[((M64) >> 6) * a.Q + q_];                                   \
-            NZ[t] = a.b_nz[((M64) >> 6) * a.Q + q_];                                     \
+            SG[t] = sg_[qcol[t]];                                                        \
+            NZ[t] = nz_[qcol[t]] & slot_live[t];                                         \
         }                                                                                \
     } while (0)
-// rows past M read the last row; their plane bits are 0 (written so by the producers), so they contribute nothing
-#define SVNET_TN_LOAD_A(MROW)                                                            \
+// k-step of 16 rows from uniform row M16: lane (r, h) takes rows M16 + 8h .. + 7 of column p.  Rows past M (last k-step only)
+// read the last row; their plane bits are 0 (written so by the producers), so they contribute nothing.
+#define SVNET_TN_LOAD_A(S, M16)                                                          \
     do {                                                                                 \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) xn[j] = a.A[min((MROW) + j, mlast) * a.lda + p]; \
+        if ((M16) + 16 <= a.M) {                                                         \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) xn[(S) * 8 + j] = (a.A + ((M16) + j) * a.lda)[lane_off]; \
+        } else {                                                                         \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) xn[(S) * 8 + j] = a.A[min((M16) + 8 * h + j, mlast) * a.lda + p]; \
+        }                                                                                \
     } while (0)
         constexpr bool PFW = NQ <= 5;   // plane words of the next block in flight too (register budget permitting)
         if (PFW) SVNET_TN_WORDS(mb, nsg, nnz);
-        SVNET_TN_LOAD_A(mb + 8 * h);
+#pragma unroll
+        for (int s = 0; s < NPF; ++s) SVNET_TN_LOAD_A(s, mb + 16 * s);
         for (int64_t m64 = mb; m64 < me; m64 += 64) {
             if (PFW) {
 #pragma unroll
@@ -410,28 +428,37 @@ __global__ __launch_bounds__(256, 2) void mfma_tn_tern_kernel(TnArgs a) {
                 SVNET_TN_WORDS(m64, wsg, wnz);
             }
 #pragma unroll
-            for (int s16 = 0; s16 < 64; s16 += 16) {
+            for (int s = 0; s < 4; ++s) {
+                const int s16 = 16 * s;
                 if (m64 + s16 >= me) break;  // wave-uniform
-                float x[8];
+                float x[8];      // (every row range ends on a multiple of 64 or at M, and rows past M have empty planes: no masking)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = (m64 + s16 + 8 * h + j < me) ? xn[j] : 0.f;   // rows of the next sub-range are not mine
-                if (m64 + s16 + 16 < me) SVNET_TN_LOAD_A(m64 + s16 + 16 + 8 * h);
+                for (int j = 0; j < 8; ++j) x[j] = xn[(s % NPF) * 8 + j];
                 const Split3 sa = split_frag(x);
+                if (m64 + s16 + 16 * NPF < me) SVNET_TN_LOAD_A(s % NPF, m64 + s16 + 16 * NPF);   // NPF k-steps ahead, into the registers just consumed
                 const int sh = s16 + 8 * h;
+                // No per-tile branches in here: a slot without a live tile has its non-zero plane forced to 0 (SVNET_TN_WORDS),
+                // so the whole k-step is one basic block and the LDS lookups of one tile overlap the MFMAs of another.
+                constexpr int TG = NQ <= 5 ? NQ : 2;   // tiles expanded together (4 VGPRs each)
 #pragma unroll
-                for (int t = 0; t < NQ; ++t) {
-                    const int qt = SVNET_QT(t);
-                    if (qt < 0 || qt * 32 >= a.Q) continue;               // no such tile (uniform)
-                    if (!((a.qmask >> qt) & 1u)) continue;                // a tile of padding columns (uniform)
-                    const uint32_t nzb = (uint32_t)(wnz[t] >> sh) & 0xFFu;
-                    const uint32_t ngb = nzb & ~(uint32_t)(wsg[t] >> sh);
-                    const uint4 mg = *reinterpret_cast<const uint4*>(&lut_mag[nzb * 4]);
-                    const uint4 ng = *reinterpret_cast<const uint4*>(&lut_neg[ngb * 4]);
-                    const uint4 bw = make_uint4(mg.x | ng.x, mg.y | ng.y, mg.z | ng.z, mg.w | ng.w);
-                    const bf16x8 b = __builtin_bit_cast(bf16x8, bw);
-                    acc[t] = MFMA(sa.h, b, acc[t]);
-                    acc[t] = MFMA(sa.m, b, acc[t]);
-                    acc[t] = MFMA(sa.l, b, acc[t]);
+                for (int t0 = 0; t0 < NQ; t0 += TG) {
+                    bf16x8 bfr[TG];
+#pragma unroll
+                    for (int u = 0; u < TG; ++u) {
+                        const int t = t0 + u;
+                        const uint32_t nzb = (uint32_t)(wnz[t] >> sh) & 0xFFu;
+                        const uint32_t ngb = nzb & ~(uint32_t)(wsg[t] >> sh);
+                        const uint4 mg = *reinterpret_cast<const uint4*>(&lut_mag[nzb * 4]);
+                        const uint4 ng = *reinterpret_cast<const uint4*>(&lut_neg[ngb * 4]);
+                        const uint4 bw = make_uint4(mg.x | ng.x, mg.y | ng.y, mg.z | ng.z, mg.w | ng.w);
+                        bfr[u] = __builtin_bit_cast(bf16x8, bw);
+                    }
+#pragma unroll
+                    for (int u = 0; u < TG; ++u) acc[t0 + u] = MFMA(sa.h, bfr[u], acc[t0 + u]);
+#pragma unroll
+                    for (int u = 0; u < TG; ++u) acc[t0 + u] = MFMA(sa.m, bfr[u], acc[t0 + u]);
+#pragma unroll
+                    for (int u = 0; u < TG; ++u) acc[t0 + u] = MFMA(sa.l, bfr[u], acc[t0 + u]);
                 }
             }
         }
@@ -511,7 +538,8 @@ void launch_tn(TnArgs a, hipStream_t st) {
     const int gy = (int)svnet_cdiv(ptiles, a.ptiles_per_block);
     // ~4 workgroups per CU in total; 2 when the output is large (every row split ends in P*Q float atomics, which the memory
     // side executes at ~1 TB/s: conv5's 512 x 505 gradient spent half its time there with 128 splits)
-    const int64_t target = ((int64_t)a.P * a.Q >= 128 * 1024) ? 512 : 1024;
+    int64_t target = (BMODE == 1 || (int64_t)a.P * a.Q >= 128 * 1024) ? 512 : 1024;   // ternary: exactly one resident round (2 per CU)
+    if (const char* e = getenv("SVNET_TN_TARGET")) target = atoi(e);
     int64_t want = svnet_cdiv(target, (int64_t)gy * gz);
     int64_t rpb = svnet_cdiv(svnet_cdiv(a.M, want), 256) * 256;
     if (rpb < 256) rpb = 256;
