@@ -219,8 +219,9 @@ int64_t svnet_edgeblock_msg_stride(int64_t Cs, int64_t Cv, int64_t Ov);
  * dv_acc [P,3,Cv] +=, dbeta1 [2Cs+6Cv] = dbeta_perm in the reference's feature order.                                  */
 int svnet_edgeblock_bwd_gather_f32(const float* msg, const int32_t* rev_range, const int32_t* rev_edge, const int32_t* rev_src,
                                    const float* ut, const float* ub_tab, const float* ge_tab, const float* coef, const float* bcoef,
-                                   int64_t Os, const float* dvc,
-                                   const float* dzc, int64_t P, int64_t Cs, int64_t Cv, int64_t Ov, float* acat,
+                                   int64_t Os, const float* dvc, const float* dzc, int64_t P /* = B*N points */,
+                                   int64_t N /* points per cloud (sets the XCD-aware point order) */, int64_t Cs, int64_t Cv,
+                                   int64_t Ov, float* acat,
                                    int64_t acat_ld /* row stride of acat, >= 2Ov+6 (a multiple of 4 keeps the GEMM's loads 16-byte) */,
                                    float* ds_acc, float* dv_acc, const float* dbeta_perm, float* dbeta1, void* stream);
 /* STE chain rule (svnet_binweight_grad_f32's formula, ASSIGNED) for linear1 from GXp [Os,320] (fused column order), for

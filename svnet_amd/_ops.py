@@ -749,7 +749,7 @@ class EdgeBlock(torch.autograd.Function):
              tern_tile_mask=used)
         with torch.cuda.stream(side):
             call("svnet_edgeblock_bwd_gather_f32", _p(msg), _p(rev_range), _p(rev_edge), _p(rev_src), _p(ut), _p(ub_tab), _p(ge_tab),
-                 _p(coef), _p(bcoef), Os, _p(dvc), _p(dzc), P, Cs, Cv, Ov, _p(acat), Rp, _p(ds_acc), _p(dv_acc), _p(dbeta_perm),
+                 _p(coef), _p(bcoef), Os, _p(dvc), _p(dzc), P, N, Cs, Cv, Ov, _p(acat), Rp, _p(ds_acc), _p(dv_acc), _p(dbeta_perm),
                  _p(dbeta1), _stream())
             # linear2 and the v2s frame: dv += (acat * scv) . wv ;  GXc = acat^T . v
             gemm(3 * P, Cv, R, A=acat, a_rs=Rp, a_cs=1, a_scale=scv, B=wv, b_rs=Cv, b_cs=1, b_exact=True, C=dv_acc, ldc=Cv, accumulate=True)

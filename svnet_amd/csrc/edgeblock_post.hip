@@ -137,12 +137,19 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_gather_kernel(const float* 
                                                                    const float* __restrict__ ut, const float* __restrict__ ub_tab,
                                                                    const float* __restrict__ ge_tab, const float* __restrict__ coef,
                                                                    const float* __restrict__ bcoef, int Os, const float* __restrict__ dvc,
-                                                                   const float* __restrict__ dzc, int64_t P, int Cs, int Cv, int Ov, int R,
+                                                                   const float* __restrict__ dzc, int64_t P, int bpc, int Cs, int Cv, int Ov, int R,
                                                                    float* __restrict__ acat, int RW, float* __restrict__ ds_acc,
                                                                    float* __restrict__ dv_acc, const float* __restrict__ dbeta_perm,
                                                                    float* __restrict__ dbeta1) {
     const int lane = threadIdx.x & 63;
-    const int64_t j = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // XCD-aware order (bpc = workgroups per cloud, 0 = off): workgroups b and b+8 share an XCD, so XCD x walks the clouds
+    // x, x+8, ... one after the other and the cloud's ub/ge tables (1 MB at Ov = 42) are served from that XCD's L2
+    int64_t blk = blockIdx.x;
+    if (bpc > 0) {
+        const int64_t xcd = blk & 7, slot = blk >> 3;
+        blk = ((slot / bpc) * 8 + xcd) * bpc + (slot % bpc);
+    }
+    const int64_t j = blk * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (blockIdx.x == 0) {       // dL/dbeta from the fused column order back to the reference's feature order
         const int K1 = 2 * Cs + 6 * Cv;
         for (int f = threadIdx.x; f < K1; f += blockDim.x) {
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_gather_kernel(const float* 
     }
     if (j >= P) return;
     const int beg = rev_range[2 * j], end = rev_range[2 * j + 1];
-    float acc[NCH], nx[NCH];
+    float acc[NCH];
 #pragma unroll
     for (int q = 0; q < NCH; ++q) acc[q] = 0.f;
     int col[NCH];
@@ -165,14 +172,16 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_gather_kernel(const float* 
     const float avc = Av[o], bvc = Av[Ov + o], c0 = C0[o], c1 = C0[Ov + o];
     const float uj0 = ut[(j * 3 + 0) * 2 * Ov + o], uj1 = ut[(j * 3 + 1) * 2 * Ov + o], uj2 = ut[(j * 3 + 2) * 2 * Ov + o];
     float ua0 = 0.f, ua1 = 0.f, ua2 = 0.f;
-    float tb[6], t2[6];
-#define SVNET_GATHER_LOAD(N_, ROWV, TABV)                                                               \
+    // A ring of four (row, tables) slots with compile-time indices, requested three entries ahead: rotating the prefetched
+    // registers instead (x = next; next = load) makes every copy wait for the load it reads, i.e. one full latency per entry.
+    float rw[4][NCH], tb[4][6];
+#define SVNET_GATHER_LOAD(N_, SLOT)                                                                     \
     do {                                                                                                \
         const float* row_ = msg + (int64_t)__builtin_amdgcn_readlane(ev, (N_)) * R;                     \
-        _Pragma("unroll") for (int q = 0; q < NCH; ++q) ROWV[q] = row_[col[q]];                         \
+        _Pragma("unroll") for (int q = 0; q < NCH; ++q) rw[SLOT][q] = row_[col[q]];                     \
         const int64_t si_ = (int64_t)__builtin_amdgcn_readlane(sv, (N_)) * 3 * Ov + o;                  \
-        TABV[0] = ub_tab[si_]; TABV[1] = ub_tab[si_ + Ov]; TABV[2] = ub_tab[si_ + 2 * Ov];              \
-        TABV[3] = ge_tab[si_]; TABV[4] = ge_tab[si_ + Ov]; TABV[5] = ge_tab[si_ + 2 * Ov];              \
+        tb[SLOT][0] = ub_tab[si_]; tb[SLOT][1] = ub_tab[si_ + Ov]; tb[SLOT][2] = ub_tab[si_ + 2 * Ov];  \
+        tb[SLOT][3] = ge_tab[si_]; tb[SLOT][4] = ge_tab[si_ + Ov]; tb[SLOT][5] = ge_tab[si_ + 2 * Ov];  \
     } while (0)
     // the list's edge ids / source points come in with one coalesced load each per 64 entries (lane n holds entry n, handed to
     // the scalar unit by v_readlane), so a row's loads never wait on a load of their own index
@@ -180,28 +189,33 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_gather_kernel(const float* 
         const int cnt = min(64, end - base);
         const int ev = rev_edge[base + min(lane, cnt - 1)];
         const int sv = rev_src[base + min(lane, cnt - 1)];
-        float n2[NCH];
-        SVNET_GATHER_LOAD(0, nx, tb);
-        if (cnt > 1) SVNET_GATHER_LOAD(1, n2, t2);
-        for (int n = 0; n < cnt; ++n) {
-            float cur[NCH], tc[6];
+        // The loop body has no branches (the waitcnt pass gives up on the ring when it has to merge paths): entries past the
+        // end re-request the list's last entry (cache hits) and are weighted 0.
+        const int last = cnt - 1;
+        SVNET_GATHER_LOAD(0, 0);
+        SVNET_GATHER_LOAD(min(1, last), 1);
+        SVNET_GATHER_LOAD(min(2, last), 2);
+        for (int n4 = 0; n4 < cnt; n4 += 4) {
 #pragma unroll
-            for (int q = 0; q < NCH; ++q) { cur[q] = nx[q]; nx[q] = n2[q]; }
+            for (int u = 0; u < 4; ++u) {
+                const int n = n4 + u;
+                SVNET_GATHER_LOAD(min(n + 3, last), (u + 3) & 3);
+                __builtin_amdgcn_sched_barrier(0);                     // the requests go out HERE, not next to their first use
+                const float w = n < cnt ? 1.f : 0.f;                   // wave-uniform
 #pragma unroll
-            for (int q = 0; q < 6; ++q) { tc[q] = tb[q]; tb[q] = t2[q]; }
-            if (n + 2 < cnt) SVNET_GATHER_LOAD(n + 2, n2, t2);
-#pragma unroll
-            for (int q = 0; q < NCH; ++q) acc[q] += cur[q];
-            // dv' of the edge (source i -> this point): same arithmetic as edgeblock_bwd_vec_kernel
-            const float vp0 = uj0 + tc[0], vp1 = uj1 + tc[1], vp2 = uj2 + tc[2];
-            const float nv = fast_sqrt(vp0 * vp0 + vp1 * vp1 + vp2 * vp2);
-            const float nn = nv + 1e-6f;
-            const float rn = fast_rcp(nn);
-            const float qq = avc + bvc * rn;
-            const float gdot = tc[3] * vp0 + tc[4] * vp1 + tc[5] * vp2;
-            const float dnn = -gdot * bvc * rn * rn + c0 + c1 * nn;
-            const float kk = nv > 0.f ? dnn * fast_rcp(nv) : 0.f;
-            ua0 += tc[3] * qq + kk * vp0; ua1 += tc[4] * qq + kk * vp1; ua2 += tc[5] * qq + kk * vp2;
+                for (int q = 0; q < NCH; ++q) acc[q] += w * rw[u][q];
+                const float* tc = tb[u];
+                // dv' of the edge (source i -> this point): same arithmetic as edgeblock_bwd_vec_kernel
+                const float vp0 = uj0 + tc[0], vp1 = uj1 + tc[1], vp2 = uj2 + tc[2];
+                const float nv = fast_sqrt(vp0 * vp0 + vp1 * vp1 + vp2 * vp2);
+                const float nn = nv + 1e-6f;
+                const float rn = fast_rcp(nn);
+                const float qq = (avc + bvc * rn) * w;
+                const float gdot = tc[3] * vp0 + tc[4] * vp1 + tc[5] * vp2;
+                const float dnn = -gdot * bvc * rn * rn + c0 + c1 * nn;
+                const float kk = dnn * fast_rcp(fmaxf(nv, 1e-30f)) * (nv > 0.f ? w : 0.f);   // (a select, not a branch)
+                ua0 += tc[3] * qq + kk * vp0; ua1 += tc[4] * qq + kk * vp1; ua2 += tc[5] * qq + kk * vp2;
+            }
         }
     }
 #undef SVNET_GATHER_LOAD
@@ -273,21 +287,22 @@ extern "C" int svnet_knn_reverse_i32(const int64_t* idx, int64_t B, int64_t N, i
 
 extern "C" int svnet_edgeblock_bwd_gather_f32(const float* msg, const int32_t* rev_range, const int32_t* rev_edge, const int32_t* rev_src,
                                               const float* ut, const float* ub_tab, const float* ge_tab, const float* coef,
-                                              const float* bcoef, int64_t Os, const float* dvc, const float* dzc, int64_t P, int64_t Cs,
-                                              int64_t Cv, int64_t Ov, float* acat, int64_t acat_ld, float* ds_acc, float* dv_acc,
+                                              const float* bcoef, int64_t Os, const float* dvc, const float* dzc, int64_t P, int64_t N,
+                                              int64_t Cs, int64_t Cv, int64_t Ov, float* acat, int64_t acat_ld, float* ds_acc, float* dv_acc,
                                               const float* dbeta_perm, float* dbeta1, void* stream) {
     SVNET_REQUIRE(msg && rev_range && rev_edge && rev_src && ut && ub_tab && ge_tab && coef && bcoef && dvc && dzc && acat && ds_acc &&
-                      dv_acc && dbeta_perm && dbeta1 && P > 0 && Os > 0, SVNET_E_ARG, "svnet_edgeblock_bwd_gather_f32: bad arguments");
+                      dv_acc && dbeta_perm && dbeta1 && P > 0 && N > 0 && P % N == 0 && Os > 0, SVNET_E_ARG, "svnet_edgeblock_bwd_gather_f32: bad arguments");
     SVNET_REQUIRE(acat_ld >= 2 * Ov + 6, SVNET_E_ARG, "svnet_edgeblock_bwd_gather_f32: acat_ld < 2*Ov + 6");
     SVNET_REQUIRE(Cs > 0 && Cs <= 64 && Cv > 0 && 2 * Cv <= 64 && Ov > 0 && Ov <= 64, SVNET_E_UNSUPPORTED,
                   "svnet_edgeblock_bwd_gather_f32: needs Cs <= 64, 2*Cv <= 64, Ov <= 64");
     const int R = (int)svnet_edgeblock_msg_stride(Cs, Cv, Ov);
     const int nch = (R + 63) / 64;
     const unsigned grid = (unsigned)svnet_cdiv(P, 4);
+    const int bpc = ((P / N) % 8 == 0 && N % 4 == 0) ? (int)(N / 4) : 0;   // clouds in groups of 8, whole workgroups per cloud
     hipStream_t st = (hipStream_t)stream;
 #define SVNET_GATHER(NCH)                                                                                                            \
     hipLaunchKernelGGL((edgeblock_bwd_gather_kernel<NCH>), dim3(grid), dim3(256), 0, st, msg, rev_range, rev_edge, rev_src, ut, ub_tab, \
-                       ge_tab, coef, bcoef, (int)Os, dvc, dzc, P, (int)Cs, (int)Cv, (int)Ov, R, acat, (int)acat_ld, ds_acc, dv_acc,   \
+                       ge_tab, coef, bcoef, (int)Os, dvc, dzc, P, bpc, (int)Cs, (int)Cv, (int)Ov, R, acat, (int)acat_ld, ds_acc, dv_acc,   \
                        dbeta_perm, dbeta1)
     switch (nch) {
         case 1: SVNET_GATHER(1); break;
