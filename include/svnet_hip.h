@@ -123,7 +123,7 @@ int svnet_binweight_grad_f32(const float* GX, const float* W, const float* scale
  *   zz [P,3,6]    = [Zp | Zq],  Zp = v . (scale_z*sign(Wz[:, :Cv]))^T,  Zq = v . (scale_z*sign(Wz[:, Cv:]))^T   (v2s frame)
  *   ut [P,3,2Ov]  = [U  | T ],  U  = v . (scale2*sign(W2[:, :Cv]))^T,   T  = v . (scale2*sign(W2[:, Cv:]))^T    (linear2)
  * linear1's sign planes / beta are permuted once into the kernel's bit order (5 words: s_j-s_i | s_i | s_v[:,0] |
- * s_v[:,1] | s_v[:,2]) by svnet_edgeblock_prepare_f32.  Limits: Cs <= 64, 2*Cv <= 64, Os <= 128, Ov <= 64, k <= 64.
+ * s_v[:,1] | s_v[:,2]) by svnet_edgeblock_prepare_f32.  Limits: Cs <= 64, 2*Cv <= 64, Os <= 128, Ov <= 64, k <= 64 (backward: 2 <= k).
  * Per-point outputs: n_max/n_min [P,Os] (extreme integer popcount sums over the k neighbours) with their slots,
  * mv/mvn [P,3,Ov] (mean_k v', mean_k v'/|v'|); batch statistics as exact integer sums stat_n [2*Os] (sum n, sum n^2)
  * and fp64 sums stat_v [2*Ov]; gate_sum [B,2Cs] = sum over the cloud's edges of [s_j-s_i, s_i] (caller zero-fills

@@ -299,8 +299,15 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_vec_kernel(VecArgs va) {
 struct EdgeIn {
     uint32_t gp, gj;                              // global point ids (P * 384 < 2^32 is checked on the host: 32-bit row offsets)
     bool valid;
-    float vi0, vi1, vi2, vj0, vj1, vj2;           // lane c2 < 2Cv (vj: diff lanes only)
-    float z0, z1, z2, z3, z4, z5, z6, z7, z8;     // z[d*3+jz] = Zp_j - Zp_i + Zq_i
+    float vj0, vj1, vj2;                          // neighbour's v (diff lanes only)
+    float zj[9];                                  // Zp_j, RAW: anything computed from a load at request time waits for it there
+};
+// What phase C2 needs from the edge's OWN point: it changes once per k edges, so it is requested when the ring first meets
+// the point (two iterations before its first edge is consumed) and turned into (vi, zc = Zq_i - Zp_i) when that edge is.
+// One pending set is enough for k >= 3: the next point's first edge is requested after this one's has been consumed.
+struct PointIn {
+    float vi0, vi1, vi2;                          // lane c2 < 2Cv
+    float zi[18];                                 // [Zp | Zq] rows interleaved as in zz (raw)
 };
 
 // Row cursor of a wave: edge id, its point / cloud / slot, advanced one edge at a time (no divisions, 32-bit scalar math: the
@@ -329,36 +336,45 @@ __device__ __forceinline__ void cursor_next(const svnet_edgeblock_bwd_desc& d, E
     }
 }
 
-// jloc: the edge's neighbour id (wave-uniform, from the wave's pre-loaded id vector)
+__device__ __forceinline__ void load_point(const svnet_edgeblock_bwd_desc& d, uint32_t gp, bool v2_lane, int cm, PointIn& pt) {
+    const uint32_t Cv = (uint32_t)d.Cv, lc = v2_lane ? (uint32_t)cm : 0u;
+    const uint32_t oi = gp * 3u * Cv + lc;
+    pt.vi0 = d.v[oi];
+    pt.vi1 = d.v[oi + Cv];
+    pt.vi2 = d.v[oi + 2u * Cv];
+    const float* zi = d.zz + gp * 18u;
+#pragma unroll
+    for (int q = 0; q < 18; ++q) pt.zi[q] = zi[q];
+}
+
+// jloc: the edge's neighbour id (wave-uniform, from the wave's pre-loaded id vector); loaded_p: the point whose PointIn was
+// requested last (wave-uniform)
 __device__ __forceinline__ void load_edge(const svnet_edgeblock_bwd_desc& d, const EdgeCursor& c, int jloc, int64_t E, int lane,
-                                          bool v2_lane, int cm, EdgeIn& in) {
+                                          bool v2_lane, int cm, EdgeIn& in, PointIn& pend, uint32_t& loaded_p) {
     const uint32_t Cv = (uint32_t)d.Cv, N = (uint32_t)d.N;
-    in.valid = c.e < E;
-    if (!in.valid) return;
-    in.gp = c.gp;
-    if ((uint32_t)jloc >= N) {  // corrupted neighbour id: never dereference it
-        if (d.debug && lane == 0) {
-            if (atomicAdd(reinterpret_cast<unsigned long long*>(d.debug), 1ull) == 0ull) { d.debug[1] = c.e; d.debug[2] = jloc; d.debug[3] = d.N; }
-        }
-        in.valid = false;
-        return;
+    // EVERY edge row issues its loads, rows past E and rows with a corrupted neighbour id from clamped addresses (point 0 /
+    // neighbour 0 of the cloud), and is masked where it is consumed: with a path on which a ring slot's loads are skipped or
+    // never consumed, the compiler's waitcnt pass drains the whole queue before it refills the slot.
+    const bool in_range = c.e < E;
+    const bool j_ok = (uint32_t)jloc < N;
+    if (in_range && !j_ok && d.debug && lane == 0) {
+        if (atomicAdd(reinterpret_cast<unsigned long long*>(d.debug), 1ull) == 0ull) { d.debug[1] = c.e; d.debug[2] = jloc; d.debug[3] = d.N; }
     }
-    in.gj = c.b * N + (uint32_t)jloc;
+    in.valid = in_range && j_ok;
+    in.gp = in_range ? c.gp : 0u;
+    if (in_range && c.gp != loaded_p) { load_point(d, c.gp, v2_lane, cm, pend); loaded_p = c.gp; }
+    in.gj = in.valid ? c.b * N + (uint32_t)jloc : 0u;
     // clamped lane indices: every lane issues every load (no exec-masked branches, loads go out back to back);
     // lanes outside a channel range read a valid neighbour element that is masked where it is consumed
-    const uint32_t ld = (uint32_t)min(lane, (int)Cv - 1), lc = v2_lane ? (uint32_t)cm : 0u;
-    const uint32_t oi = in.gp * 3u * Cv + lc, oj = in.gj * 3u * Cv + ld;
-    in.vi0 = d.v[oi];
-    in.vi1 = d.v[oi + Cv];
-    in.vi2 = d.v[oi + 2u * Cv];
+    const uint32_t ld = (uint32_t)min(lane, (int)Cv - 1);
+    const uint32_t oj = in.gj * 3u * Cv + ld;
     in.vj0 = d.v[oj];
     in.vj1 = d.v[oj + Cv];
     in.vj2 = d.v[oj + 2u * Cv];
-    const float* zi = d.zz + in.gp * 18u;
     const float* zj = d.zz + in.gj * 18u;
-    in.z0 = zj[0] + (zi[3] - zi[0]);    in.z1 = zj[1] + (zi[4] - zi[1]);    in.z2 = zj[2] + (zi[5] - zi[2]);
-    in.z3 = zj[6] + (zi[9] - zi[6]);    in.z4 = zj[7] + (zi[10] - zi[7]);   in.z5 = zj[8] + (zi[11] - zi[8]);
-    in.z6 = zj[12] + (zi[15] - zi[12]); in.z7 = zj[13] + (zi[16] - zi[13]); in.z8 = zj[14] + (zi[17] - zi[14]);
+    in.zj[0] = zj[0];  in.zj[1] = zj[1];  in.zj[2] = zj[2];
+    in.zj[3] = zj[6];  in.zj[4] = zj[7];  in.zj[5] = zj[8];
+    in.zj[6] = zj[12]; in.zj[7] = zj[13]; in.zj[8] = zj[14];
 }
 
 // MODE: 0 = product; 1..3 = timing-only ablations (SVNET_BWD_MODE), wrong results.  NKS = k-steps of phase B (Os <= 16*NKS)
@@ -652,6 +668,11 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
     // ================= phase C2 (lanes = vector channels, one edge per wave iteration): v2s backward =================
     {
         uint32_t cur_p = 0xFFFFFFFFu;               // "no point yet"
+        uint32_t loaded_p = 0xFFFFFFFFu;            // point whose PointIn is pending
+        PointIn pend;
+        float vi0 = 0.f, vi1 = 0.f, vi2 = 0.f, zc[9];   // the current point's v (masked per lane class below) and Zq_i - Zp_i
+#pragma unroll
+        for (int q = 0; q < 9; ++q) zc[q] = 0.f;
         const uint32_t uCv = (uint32_t)Cv;
         float* const mrow0 = d.msg + ew * R + Cs;   // message row of this wave's first edge (the only 64-bit product)
         float cvd0 = 0.f, cvd1 = 0.f, cvd2 = 0.f;   // centre part of dv (diff lanes carry -sum, centre lanes +sum)
@@ -676,39 +697,50 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
         EdgeIn q[4];
         EdgeCursor cur;
         cursor_init(d, ew, cur);
-        load_edge(d, cur, __builtin_amdgcn_readlane(jv8, 0), E, lane, v2_lane, cm, q[0]);
+        load_edge(d, cur, __builtin_amdgcn_readlane(jv8, 0), E, lane, v2_lane, cm, q[0], pend, loaded_p);
+        if (loaded_p != 0xFFFFFFFFu && cur.t + 1 == (int)d.k) {
+            // the wave's second edge already starts another point: take the first point's operands now (this waits for them)
+            cur_p = loaded_p;
+            vi0 = pend.vi0; vi1 = pend.vi1; vi2 = pend.vi2;
+#pragma unroll
+            for (int q9 = 0; q9 < 9; ++q9) zc[q9] = pend.zi[(q9 / 3) * 6 + 3 + q9 % 3] - pend.zi[(q9 / 3) * 6 + q9 % 3];
+        }
         cursor_next(d, cur);
-        load_edge(d, cur, __builtin_amdgcn_readlane(jv8, 1), E, lane, v2_lane, cm, q[1]);
+        load_edge(d, cur, __builtin_amdgcn_readlane(jv8, 1), E, lane, v2_lane, cm, q[1], pend, loaded_p);
 #pragma unroll 1
         for (int r4 = 0; r4 < TE / 4; r4 += 4) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int rr = r4 + u;
             const int r = wave * (TE / 4) + rr;
-            q[(u + 2) & 3].valid = false;
-            if (rr + 2 < TE / 4) {
-                cursor_next(d, cur);
-                load_edge(d, cur, __builtin_amdgcn_readlane(jv8, rr + 2), E, lane, v2_lane, cm, q[(u + 2) & 3]);
-            }
             const EdgeIn& in = q[u];
-            if (!in.valid) continue;
-            const uint32_t gp = in.gp;
-            if (gp != cur_p) {
+            // the current edge's point operands are taken BEFORE the requests of this iteration go out (they may re-use `pend`)
+            if (in.valid && in.gp != cur_p) {
                 if (cur_p != 0xFFFFFFFFu) SVNET_FLUSH_POINT(cur_p);
-                cur_p = gp;
+                cur_p = in.gp;
                 cvd0 = cvd1 = cvd2 = 0.f;
                 czq = czq8 = 0.f;
+                vi0 = pend.vi0; vi1 = pend.vi1; vi2 = pend.vi2;
+#pragma unroll
+                for (int q9 = 0; q9 < 9; ++q9) zc[q9] = pend.zi[(q9 / 3) * 6 + 3 + q9 % 3] - pend.zi[(q9 / 3) * 6 + q9 % 3];
             }
+            // (the last two requests of the wave repeat its last row: nothing consumes them)
+            cursor_next(d, cur);
+            load_edge(d, cur, __builtin_amdgcn_readlane(jv8, min(rr + 2, TE / 4 - 1)), rr + 2 < TE / 4 ? E : 0, lane, v2_lane, cm,
+                      q[(u + 2) & 3], pend, loaded_p);
             const float* row = dxl + r * DXS;
-            const float g0 = v2_lane ? row[2 * Cs + lane] : 0.f, g1 = v2_lane ? row[2 * Cs + 2 * Cv + lane] : 0.f,
-                        g2 = v2_lane ? row[2 * Cs + 4 * Cv + lane] : 0.f;
+            const bool live = v2_lane && in.valid;   // rows past E / dropped edges contribute zeros and store nothing
+            const float g0 = live ? row[2 * Cs + lane] : 0.f, g1 = live ? row[2 * Cs + 2 * Cv + lane] : 0.f,
+                        g2 = live ? row[2 * Cs + 4 * Cv + lane] : 0.f;
+            const float z0 = in.zj[0] + zc[0], z1 = in.zj[1] + zc[1], z2 = in.zj[2] + zc[2], z3 = in.zj[3] + zc[3], z4 = in.zj[4] + zc[4],
+                        z5 = in.zj[5] + zc[5], z6 = in.zj[6] + zc[6], z7 = in.zj[7] + zc[7], z8 = in.zj[8] + zc[8];
             // v2s backward: s_v[c2][jz] = sum_d ve[d][c2] * z[d][jz]
-            const float ve0 = diff_lane ? (in.vj0 - in.vi0) : (v2_lane ? in.vi0 : 0.f);
-            const float ve1 = diff_lane ? (in.vj1 - in.vi1) : (v2_lane ? in.vi1 : 0.f);
-            const float ve2 = diff_lane ? (in.vj2 - in.vi2) : (v2_lane ? in.vi2 : 0.f);
-            const float dve0 = g0 * in.z0 + g1 * in.z1 + g2 * in.z2;
-            const float dve1 = g0 * in.z3 + g1 * in.z4 + g2 * in.z5;
-            const float dve2 = g0 * in.z6 + g1 * in.z7 + g2 * in.z8;
+            const float ve0 = diff_lane ? (in.vj0 - vi0) : (v2_lane ? vi0 : 0.f);
+            const float ve1 = diff_lane ? (in.vj1 - vi1) : (v2_lane ? vi1 : 0.f);
+            const float ve2 = diff_lane ? (in.vj2 - vi2) : (v2_lane ? vi2 : 0.f);
+            const float dve0 = g0 * z0 + g1 * z1 + g2 * z2;
+            const float dve1 = g0 * z3 + g1 * z4 + g2 * z5;
+            const float dve2 = g0 * z6 + g1 * z7 + g2 * z8;
             // dL/dz[d][jz] = sum over the lanes of g_jz * ve_d: nine wave-wide sums, eight of them packed
             const float pz[8] = {g0 * ve0, g1 * ve0, g2 * ve0, g0 * ve1, g1 * ve1, g2 * ve1, g0 * ve2, g1 * ve2};
             const float dzp = wave_sum8_packed(pz, lane);
@@ -718,7 +750,7 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
             if (diff_lane) { cvd0 -= dve0; cvd1 -= dve1; cvd2 -= dve2; }
             else if (v2_lane) { cvd0 += dve0; cvd1 += dve1; cvd2 += dve2; }
             // ---- the neighbour's share: plain stores into the edge's message row
-            {
+            if (in.valid) {
                 float* m = mrow0 + (uint32_t)rr * (uint32_t)R;
                 if (diff_lane) { m[lane] = dve0; m[Cv + lane] = dve1; m[2 * Cv + lane] = dve2; }
                 if (zq_writer) m[3 * Cv + zq_idx] = dzp;
@@ -777,7 +809,7 @@ extern "C" int svnet_edgeblock_bwd_f32(const svnet_edgeblock_bwd_desc* desc, voi
                       d.gate && d.gy && d.bcoef && d.gv && d.gconst && d.dn_out && d.x_sign32 && d.x_nz32 && d.ds_acc && d.dv_acc &&
                       d.msg && d.dvc && d.dzc && d.dbeta_perm && d.ub_tab && d.ge_tab,
                   SVNET_E_ARG, "svnet_edgeblock_bwd_f32: null pointer");
-    SVNET_REQUIRE(d.B >= 0 && d.N > 0 && d.k > 0 && d.k <= 64, SVNET_E_ARG, "svnet_edgeblock_bwd_f32: bad sizes (k <= 64)");
+    SVNET_REQUIRE(d.B >= 0 && d.N > 0 && d.k >= 2 && d.k <= 64, SVNET_E_ARG, "svnet_edgeblock_bwd_f32: bad sizes (2 <= k <= 64)");
     SVNET_REQUIRE((d.Os & (d.Os - 1)) == 0, SVNET_E_UNSUPPORTED, "svnet_edgeblock_bwd_f32: Os must be a power of two (8..128)");
     SVNET_REQUIRE(d.B * d.N * 384 < ((int64_t)1 << 32), SVNET_E_UNSUPPORTED, "svnet_edgeblock_bwd_f32: more than 11 M points (32-bit row offsets)");
     SVNET_REQUIRE(d.Cs > 0 && d.Cs <= 64 && d.Cv > 0 && 2 * d.Cv <= 64 && d.Os > 0 && d.Os <= 128 && d.Os % 8 == 0 && d.Ov > 0 &&

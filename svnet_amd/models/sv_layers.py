@@ -260,7 +260,7 @@ class SVBlock(nn.Module):
         if not (lin1.bw and lin1.ba and lin2.bw and self.v2s.linear.bw) or edges.idx_is_global:
             return False
         Cs, Cv = edges.s.shape[-1], edges.v.shape[-1]
-        return (Cs <= 64 and 2 * Cv <= 64 and lin1.out_features <= 128 and lin2.out_features <= 64 and edges.k <= 64
+        return (Cs <= 64 and 2 * Cv <= 64 and lin1.out_features <= 128 and lin2.out_features <= 64 and 2 <= edges.k <= 64
                 and edges.s.shape[1] <= 8192 and lin1.out_features in (8, 16, 32, 64, 128) and lin1.in_features == 2 * Cs + 6 * Cv and self.bn1.track_running_stats and self.bn2.bn.track_running_stats)
 
     def forward(self, x):
