@@ -163,14 +163,17 @@ __device__ __forceinline__ void edgeblock_fwd_body(const FwdArgs& fa, const floa
         const int ls = min(lane, Cs - 1), ld = min(lane, Cv - 1), lo = min(lane, Ov - 1);
         const int opaque0 = (int)__builtin_amdgcn_mbcnt_lo(0u, 0u);
         struct Nbr { float sj, vj0, vj1, vj2, u0, u1, u2, z[9]; };
-        Nbr na, nb;
+        Nbr na = {}, nb = {};
 #define SVNET_LOAD_NBR(N_, T)                                                               \
     do {                                                                                    \
         const int64_t gj_ = b * d.N + __builtin_amdgcn_readlane(jv, (T));                   \
-        N_.sj = ts[gj_ * Cs + ls];                                                          \
-        N_.vj0 = tv[(gj_ * 3 + 0) * Cv + ld]; N_.vj1 = tv[(gj_ * 3 + 1) * Cv + ld]; N_.vj2 = tv[(gj_ * 3 + 2) * Cv + ld]; \
-        N_.u0 = tut[(gj_ * 3 + 0) * 2 * Ov + lo]; N_.u1 = tut[(gj_ * 3 + 1) * 2 * Ov + lo]; N_.u2 = tut[(gj_ * 3 + 2) * 2 * Ov + lo]; \
+        const float* ps_ = ts + gj_ * Cs + ls;                                              \
+        const float* pv_ = tv + gj_ * 3 * Cv + ld;                                          \
+        const float* pu_ = tut + gj_ * 6 * Ov + lo;                                         \
         const float* zr_ = tzz + gj_ * 18 + opaque0;                                        \
+        N_.sj = ps_[0];                                                                     \
+        N_.vj0 = pv_[0]; N_.vj1 = pv_[Cv]; N_.vj2 = pv_[2 * Cv];                            \
+        N_.u0 = pu_[0]; N_.u1 = pu_[2 * Ov]; N_.u2 = pu_[4 * Ov];                           \
         N_.z[0] = zr_[0]; N_.z[1] = zr_[1]; N_.z[2] = zr_[2]; N_.z[3] = zr_[6]; N_.z[4] = zr_[7]; N_.z[5] = zr_[8];        \
         N_.z[6] = zr_[12]; N_.z[7] = zr_[13]; N_.z[8] = zr_[14];                            \
     } while (0)
@@ -182,7 +185,8 @@ __device__ __forceinline__ void edgeblock_fwd_body(const FwdArgs& fa, const floa
 #define SVNET_EDGE(CUR, NXT, T)                                                                                              \
     do {                                                                                                                     \
         const int t = (T);                                                                                                   \
-        if (t + 1 < k) SVNET_LOAD_NBR(NXT, t + 1);                                                                           \
+        SVNET_LOAD_NBR(NXT, min(t + 1, k - 1));   /* unconditional (the last edge re-requests itself): a branch here makes */ \
+                                                  /* the waitcnt pass drain the queue, the next row's loads included       */ \
         const float sd = s_lane ? (CUR.sj - s_i) : 0.f;                                                                      \
         gs_diff += sd;                                                                                                       \
         const float td = sd + bd;                                                                                            \
@@ -230,10 +234,14 @@ __device__ __forceinline__ void edgeblock_fwd_body(const FwdArgs& fa, const floa
         }                                                                                                                    \
     } while (0)
         SVNET_LOAD_NBR(na, 0);
-        for (int t2 = 0; t2 < k; t2 += 2) {
+        // pairs without a skippable half (a path on which a slot's loads are never consumed costs a full drain per edge);
+        // an odd k ends with one more edge outside the loop
+        int t2 = 0;
+        for (; t2 + 1 < k; t2 += 2) {
             SVNET_EDGE(na, nb, t2);
-            if (t2 + 1 < k) SVNET_EDGE(nb, na, t2 + 1);
+            SVNET_EDGE(nb, na, t2 + 1);
         }
+        if (t2 < k) SVNET_EDGE(na, nb, t2);
 #undef SVNET_EDGE
 #undef SVNET_WL
 #undef SVNET_LOAD_NBR
