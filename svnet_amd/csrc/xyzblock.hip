@@ -102,8 +102,8 @@ __global__ __launch_bounds__(256) void xyzblock_fwd_kernel(XyzFwdArgs fa) {
         }
         for (int t = 0; t < k; ++t) {
             const float xj[3] = {xn[0], xn[1], xn[2]};
-            if (t + 1 < k) {
-                const int j1 = __builtin_amdgcn_readlane(jv, t + 1);
+            {   // unconditional (the last edge re-requests itself): a branch here makes the waitcnt pass drain the request it guards
+                const int j1 = __builtin_amdgcn_readlane(jv, min(t + 1, k - 1));
                 xn[0] = xb[j1]; xn[1] = xb[N + j1]; xn[2] = xb[2 * N + j1];
             }
             EdgeFeat e;
@@ -299,8 +299,8 @@ __global__ __launch_bounds__(256) void xyzblock_bwd_kernel(svnet_xyzblock_bwd_de
         }
         for (int t = 0; t < k; ++t) {
             const float xj[3] = {xn[0], xn[1], xn[2]};
-            if (t + 1 < k) {
-                const int j1 = __builtin_amdgcn_readlane(jv, t + 1);
+            {   // unconditional (the last edge re-requests itself): a branch here makes the waitcnt pass drain the request it guards
+                const int j1 = __builtin_amdgcn_readlane(jv, min(t + 1, k - 1));
                 xn[0] = xb[j1]; xn[1] = xb[N + j1]; xn[2] = xb[2 * N + j1];
             }
             EdgeFeat e;
