@@ -250,7 +250,7 @@ struct TnArgs {
 // workgroup); when P is narrow (ptw < 4) the spare waves split the workgroup's row range instead of idling.
 template <int NQ, int BMODE>
 __global__ __launch_bounds__(256, 2) void mfma_tn_kernel(TnArgs a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // row ranges stay in SGPRs
     const int r = lane & 31, h = lane >> 5;
     const int ptw = a.ptiles_per_block;                      // 1, 2 or 4
     const int p0 = (blockIdx.y * ptw + (wave % ptw)) * 32;
@@ -260,8 +260,6 @@ __global__ __launch_bounds__(256, 2) void mfma_tn_kernel(TnArgs a) {
     const int64_t rows_sub = ((a.rows_per_block / nsub + 63) >> 6) << 6;   // multiple of 64
     const int64_t mb = (int64_t)blockIdx.x * a.rows_per_block + (int64_t)sub * rows_sub;
     const int64_t me = min(min(a.M, (int64_t)(blockIdx.x + 1) * a.rows_per_block), mb + rows_sub);
-    const int p = p0 + r;
-    const bool p_ok = p < a.P;
 
     f32x16 acc[NQ];
 #pragma unroll
@@ -270,10 +268,12 @@ __global__ __launch_bounds__(256, 2) void mfma_tn_kernel(TnArgs a) {
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
     // fp32 x fp32 (BMODE 0 is the only mode left here; ternary B runs in mfma_tn_tern_kernel).  The A fragment and the NQ B
-    // fragments of the next 16-row step are requested before the MFMAs of the current one.
+    // fragments of the next 16-row step are requested before the MFMAs of the current one.  Columns past P / Q are computed
+    // from clamped (valid) addresses and never stored, so only rows past the range's end need zeroing, and the k-step has no
+    // per-tile branches (one basic block: the splits of one tile overlap the MFMAs of another).
     {
         const int64_t mlast = a.M - 1;
-        const int pc = min(p, a.P - 1);
+        const int pc = min(p0 + r, a.P - 1);
         int qc[NQ];
 #pragma unroll
         for (int t = 0; t < NQ; ++t) qc[t] = min(q0 + t * 32 + r, a.Q - 1);
@@ -289,18 +289,18 @@ __global__ __launch_bounds__(256, 2) void mfma_tn_kernel(TnArgs a) {
         if (mb < me) SVNET_TN0_LOAD(mb + 8 * h);
         for (int64_t m16 = mb; m16 < me; m16 += 16) {
             float x[8], y[NQ][8];
+            const int lim = (int)min((int64_t)16, me - m16) - 8 * h;   // rows of this lane's slice inside the range (32-bit compares)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const bool ok = m16 + 8 * h + j < me;            // rows of the next sub-range are not mine
-                x[j] = (ok && p_ok) ? xn[j] : 0.f;
+                const bool ok = j < lim;
+                x[j] = ok ? xn[j] : 0.f;
 #pragma unroll
-                for (int t = 0; t < NQ; ++t) y[t][j] = ok ? yn[t][j] : 0.f;
+                for (int t = 0; t < NQ; ++t) y[t][j] = yn[t][j];   // (x = 0 is enough to drop the row)
             }
             if (m16 + 16 < me) SVNET_TN0_LOAD(m16 + 16 + 8 * h);
             const Split3 sa = split_frag(x);
 #pragma unroll
             for (int t = 0; t < NQ; ++t) {
-                if (q0 + t * 32 >= a.Q) break;  // uniform
                 const Split3 sb = split_frag(y[t]);
                 acc[t] = MFMA(sa.h, sb.h, acc[t]);
                 acc[t] = MFMA(sa.h, sb.m, acc[t]);
