@@ -124,6 +124,10 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int64_t* __rest
     }
 }
 
+// (the empty asm keeps the 32->64-bit extension of the lane offset next to the load: hoisted out of the loop, instruction
+//  selection no longer sees it and falls back to a 64-bit VALU add per load instead of the SGPR-base addressing mode)
+__device__ __forceinline__ uint32_t keep_here(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
+
 // ---- neighbour sums over the reverse lists: one wave per destination point j, lanes = columns.
 //   message rows msg[e] = [ds (Cs) | dve (3 Cv) | dz (9)] are summed (NCH chunks of 64 columns);
 //   the neighbour's share of dL/dv' (v' = U_j - U_i + T_i) of every incoming edge is RECOMPUTED from U_j (own row) and the
@@ -163,11 +167,13 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_gather_kernel(const float* 
     float acc[NCH];
 #pragma unroll
     for (int q = 0; q < NCH; ++q) acc[q] = 0.f;
-    int col[NCH];
+    uint32_t col[NCH];               // unsigned 32-bit lane offsets + wave-uniform row bases: SGPR-base loads, no 64-bit VALU adds
 #pragma unroll
-    for (int q = 0; q < NCH; ++q) col[q] = min(64 * q + lane, R - 1);     // clamped: lanes past the row re-read its last column
+    for (int q = 0; q < NCH; ++q) col[q] = 4u * (uint32_t)min(64 * q + lane, R - 1);   // BYTE offsets; clamped: lanes past the row re-read its last column
     // vector path operands of this lane's channel
     const int o = min(lane, Ov - 1);
+    const uint32_t o0 = 4u * (uint32_t)o, o1 = 4u * (uint32_t)(o + Ov), o2 = 4u * (uint32_t)(o + 2 * Ov);   // byte offsets
+#define SVNET_AT(BASE, BYTES) (*reinterpret_cast<const float*>(reinterpret_cast<const char*>(BASE) + keep_here(BYTES)))
     const float* Av = coef + 4 * Os; const float* C0 = bcoef + 3 * Os;
     const float avc = Av[o], bvc = Av[Ov + o], c0 = C0[o], c1 = C0[Ov + o];
     const float uj0 = ut[(j * 3 + 0) * 2 * Ov + o], uj1 = ut[(j * 3 + 1) * 2 * Ov + o], uj2 = ut[(j * 3 + 2) * 2 * Ov + o];
@@ -178,10 +184,11 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_gather_kernel(const float* 
 #define SVNET_GATHER_LOAD(N_, SLOT)                                                                     \
     do {                                                                                                \
         const float* row_ = msg + (int64_t)__builtin_amdgcn_readlane(ev, (N_)) * R;                     \
-        _Pragma("unroll") for (int q = 0; q < NCH; ++q) rw[SLOT][q] = row_[col[q]];                     \
-        const int64_t si_ = (int64_t)__builtin_amdgcn_readlane(sv, (N_)) * 3 * Ov + o;                  \
-        tb[SLOT][0] = ub_tab[si_]; tb[SLOT][1] = ub_tab[si_ + Ov]; tb[SLOT][2] = ub_tab[si_ + 2 * Ov];  \
-        tb[SLOT][3] = ge_tab[si_]; tb[SLOT][4] = ge_tab[si_ + Ov]; tb[SLOT][5] = ge_tab[si_ + 2 * Ov];  \
+        _Pragma("unroll") for (int q = 0; q < NCH; ++q) rw[SLOT][q] = SVNET_AT(row_, col[q]);           \
+        const int64_t si_ = (int64_t)__builtin_amdgcn_readlane(sv, (N_)) * 3 * Ov;                      \
+        const float* ub_ = ub_tab + si_; const float* ge_ = ge_tab + si_;                               \
+        tb[SLOT][0] = SVNET_AT(ub_, o0); tb[SLOT][1] = SVNET_AT(ub_, o1); tb[SLOT][2] = SVNET_AT(ub_, o2); \
+        tb[SLOT][3] = SVNET_AT(ge_, o0); tb[SLOT][4] = SVNET_AT(ge_, o1); tb[SLOT][5] = SVNET_AT(ge_, o2); \
     } while (0)
     // the list's edge ids / source points come in with one coalesced load each per 64 entries (lane n holds entry n, handed to
     // the scalar unit by v_readlane), so a row's loads never wait on a load of their own index
@@ -219,6 +226,7 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_gather_kernel(const float* 
         }
     }
 #undef SVNET_GATHER_LOAD
+#undef SVNET_AT
     const int oV = Cs, oZ = oV + 3 * Cv;                               // msg row = [ds (Cs) | dve (3 Cv) | dz (9) | pad]
 #pragma unroll
     for (int q = 0; q < NCH; ++q) {
