@@ -53,4 +53,13 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 // kernels, where the correctly rounded sequences (10 instructions each) were a fifth of the instruction stream.
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// A float at wave-uniform `base` + per-lane BYTE offset, loaded with the SGPR-base addressing mode (global_load v, voff, s[base]).
+// The empty asm keeps the 32->64-bit extension of the lane offset next to the load: once it is hoisted out of a loop, instruction
+// selection no longer sees it and falls back to a 64-bit VALU add per load.
+__device__ __forceinline__ uint32_t keep_here(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ float ld_f32_sbase(const float* base, uint32_t byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + keep_here(byte_off));
+}
+
 #endif

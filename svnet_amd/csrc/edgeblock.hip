@@ -162,18 +162,20 @@ __device__ __forceinline__ void edgeblock_fwd_body(const FwdArgs& fa, const floa
         // address carries an opaque zero so that it stays a plain (broadcast) vector load instead of load + 18 readlanes.
         const int ls = min(lane, Cs - 1), ld = min(lane, Cv - 1), lo = min(lane, Ov - 1);
         const int opaque0 = (int)__builtin_amdgcn_mbcnt_lo(0u, 0u);
+        const uint32_t bs0 = 4u * (uint32_t)ls, bd0 = 4u * (uint32_t)ld, bd1 = 4u * (uint32_t)(ld + Cv), bd2 = 4u * (uint32_t)(ld + 2 * Cv),
+                       bo0 = 4u * (uint32_t)lo, bo1 = 4u * (uint32_t)(lo + 2 * Ov), bo2 = 4u * (uint32_t)(lo + 4 * Ov);
         struct Nbr { float sj, vj0, vj1, vj2, u0, u1, u2, z[9]; };
         Nbr na = {}, nb = {};
 #define SVNET_LOAD_NBR(N_, T)                                                               \
     do {                                                                                    \
         const int64_t gj_ = b * d.N + __builtin_amdgcn_readlane(jv, (T));                   \
-        const float* ps_ = ts + gj_ * Cs + ls;                                              \
-        const float* pv_ = tv + gj_ * 3 * Cv + ld;                                          \
-        const float* pu_ = tut + gj_ * 6 * Ov + lo;                                         \
+        const float* ps_ = ts + gj_ * Cs;        /* wave-uniform row bases + 32-bit lane byte offsets: SGPR-base loads */ \
+        const float* pv_ = tv + gj_ * 3 * Cv;                                               \
+        const float* pu_ = tut + gj_ * 6 * Ov;                                              \
+        N_.sj = ld_f32_sbase(ps_, bs0);                                                     \
+        N_.vj0 = ld_f32_sbase(pv_, bd0); N_.vj1 = ld_f32_sbase(pv_, bd1); N_.vj2 = ld_f32_sbase(pv_, bd2); \
+        N_.u0 = ld_f32_sbase(pu_, bo0); N_.u1 = ld_f32_sbase(pu_, bo1); N_.u2 = ld_f32_sbase(pu_, bo2); \
         const float* zr_ = tzz + gj_ * 18 + opaque0;                                        \
-        N_.sj = ps_[0];                                                                     \
-        N_.vj0 = pv_[0]; N_.vj1 = pv_[Cv]; N_.vj2 = pv_[2 * Cv];                            \
-        N_.u0 = pu_[0]; N_.u1 = pu_[2 * Ov]; N_.u2 = pu_[4 * Ov];                           \
         N_.z[0] = zr_[0]; N_.z[1] = zr_[1]; N_.z[2] = zr_[2]; N_.z[3] = zr_[6]; N_.z[4] = zr_[7]; N_.z[5] = zr_[8];        \
         N_.z[6] = zr_[12]; N_.z[7] = zr_[13]; N_.z[8] = zr_[14];                            \
     } while (0)

@@ -124,9 +124,6 @@ __global__ __launch_bounds__(1024) void knn_reverse_kernel(const int64_t* __rest
     }
 }
 
-// (the empty asm keeps the 32->64-bit extension of the lane offset next to the load: hoisted out of the loop, instruction
-//  selection no longer sees it and falls back to a 64-bit VALU add per load instead of the SGPR-base addressing mode)
-__device__ __forceinline__ uint32_t keep_here(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
 
 // ---- neighbour sums over the reverse lists: one wave per destination point j, lanes = columns.
 //   message rows msg[e] = [ds (Cs) | dve (3 Cv) | dz (9)] are summed (NCH chunks of 64 columns);
@@ -173,7 +170,7 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_gather_kernel(const float* 
     // vector path operands of this lane's channel
     const int o = min(lane, Ov - 1);
     const uint32_t o0 = 4u * (uint32_t)o, o1 = 4u * (uint32_t)(o + Ov), o2 = 4u * (uint32_t)(o + 2 * Ov);   // byte offsets
-#define SVNET_AT(BASE, BYTES) (*reinterpret_cast<const float*>(reinterpret_cast<const char*>(BASE) + keep_here(BYTES)))
+#define SVNET_AT(BASE, BYTES) ld_f32_sbase(BASE, BYTES)
     const float* Av = coef + 4 * Os; const float* C0 = bcoef + 3 * Os;
     const float avc = Av[o], bvc = Av[Ov + o], c0 = C0[o], c1 = C0[Ov + o];
     const float uj0 = ut[(j * 3 + 0) * 2 * Ov + o], uj1 = ut[(j * 3 + 1) * 2 * Ov + o], uj2 = ut[(j * 3 + 2) * 2 * Ov + o];
