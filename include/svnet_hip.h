@@ -167,6 +167,7 @@ int svnet_edgeblock_apply_f32(const int32_t* n_max, const int32_t* n_min, const 
  *   dn_out [E,Os]            dL/d(scale*n) per edge          -> GX = dn_out^T . x_b via svnet_gemm_f32 (ternary A)
  *   x_sign32/x_nz32          row-sliced planes of x_b in fused column order, [ceil(E/64), 320] uint64 viewed as uint32
  *   msg [E,R]                per-edge contributions to the NEIGHBOUR j of each edge (summed by svnet_edgeblock_bwd_gather_f32)
+ *   ub_tab, ge_tab [P,3,Ov]  per-point operands from which that kernel recomputes the neighbour's share of dL/dv'
  *   ds_acc [P,Cs], dv_acc [P,3,Cv]   centre parts of the gradients of the point tables
  *   dvc [P,3,Ov], dzc [P,3,3]  centre sums of dL/dv' and dL/dz   (dU = sum_j - dvc, dT = dvc; dZp = sum_j - dzc, dZq = dzc)
  *   dbeta_perm [320]         dL/dbeta in fused column order                                                      */
@@ -189,7 +190,7 @@ typedef struct svnet_edgeblock_bwd_desc {
     float* ub_tab; float* ge_tab; /* [P,3,Ov] each: T_i - U_i and gv_i*gate/k, written by the vector path for the gather kernel */
     float* ds_acc; float* dv_acc; float* dvc; float* dzc; float* dbeta_perm;   /* centre sums (atomics) / dvc written */
     int64_t* debug;              /* optional [4]: {count, first bad edge, its idx value, N}; edges with idx outside [0,N) are skipped */
-    int parts;                   /* 0 or 3: both kernels; 1: vector path only (the dL/dv' columns of msg, dvc); 2: scalar/tile path only.  The two
+    int parts;                   /* 0 or 3: both kernels; 1: vector path only (dvc, ub_tab, ge_tab); 2: scalar/tile path only.  The two
                                     are independent, so a caller may issue them on two streams                                   */
 } svnet_edgeblock_bwd_desc;
 int svnet_edgeblock_wbt_bf16(const uint64_t* w_sign, const uint64_t* w_nz, int64_t Os, uint16_t* wbt, void* stream);
