@@ -298,7 +298,8 @@ __global__ __launch_bounds__(256) void edgeblock_bwd_vec_kernel(VecArgs va) {
 // the zz rows go through scalar loads and SGPR-based addressing.
 struct EdgeIn {
     uint32_t gp, gj;                              // global point ids (P * 384 < 2^32 is checked on the host: 32-bit row offsets)
-    bool valid;
+    bool valid, in_range;                         // in_range: e < E; valid: also a usable neighbour id
+    uint32_t b;                                   // cloud
     float vj0, vj1, vj2;                          // neighbour's v (diff lanes only)
     float zj[9];                                  // Zp_j, RAW: anything computed from a load at request time waits for it there
 };
@@ -361,6 +362,8 @@ __device__ __forceinline__ void load_edge(const svnet_edgeblock_bwd_desc& d, con
         if (atomicAdd(reinterpret_cast<unsigned long long*>(d.debug), 1ull) == 0ull) { d.debug[1] = c.e; d.debug[2] = jloc; d.debug[3] = d.N; }
     }
     in.valid = in_range && j_ok;
+    in.in_range = in_range;
+    in.b = in_range ? c.b : 0u;
     in.gp = in_range ? c.gp : 0u;
     if (in_range && c.gp != loaded_p) { load_point(d, c.gp, v2_lane, cm, pend); loaded_p = c.gp; }
     in.gj = in.valid ? c.b * N + (uint32_t)jloc : 0u;
@@ -612,58 +615,10 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
     PHASE_MARK(2);   // phase B
     if (MODE == 3) return;
 
-    // ================= phase C1 (all 256 threads over the tile): s part and dL/dbeta =================
-    //   msg[e][c]   = dx[e][c] + gconst0[c]                                  (the neighbour's share of ds)
-    //   ds_acc[i,c] += sum over the point's edges of dx[e][64+c] + gconst1[c] - msg[e][c]
-    //   dbeta_perm  += column sums of dx
+    // (the s part - msg[e][c] = dx[e][c] + gconst0[c], ds_acc[i,c] += sum over the point's edges of dx[e][Cs+c] + gconst1[c] - msg[e][c] -
+    //  used to be a phase of its own over the whole tile (three barriers, LDS atomics): it now rides in phase C2's edge loop,
+    //  lanes = scalar channels, centre sums in a register per point)
     const int64_t R = msg_stride(Cs, Cv, d.Ov);
-    {
-        const int k = (int)d.k;
-        const int64_t e_end = min(E, e0 + TE);
-        const int64_t gp_first = e0 / k;
-        const int npt = (int)((e_end - 1) / k - gp_first) + 1;          // points touched by this tile
-        float* csl = reinterpret_cast<float*>(pl);                        // the planes are dead after phase B: [npt][Cs] centre sums
-        const bool use_lds = npt * Cs <= 3 * TE * NW * 2;                 // floats in the planes region (k >= 3 at Cs = 64)
-        __shared__ int row_slot[TE], row_gc[TE];                          // per row: point slot inside the tile (-1 past E), gconst row offset
-        if (tid < TE) {
-            const int64_t e = e0 + tid;
-            const int64_t gp = e / k;
-            row_slot[tid] = e < E ? (int)(gp - gp_first) : -1;
-            row_gc[tid] = (int)(gp / d.N) * 2 * Cs;
-        }
-        if (use_lds) for (int i = tid; i < npt * Cs; i += 256) csl[i] = 0.f;
-        __syncthreads();
-        {
-            const int cw_shift = Cs <= 32 ? 5 : 6;                        // threads = (row group, channel): shifts, no divisions
-            const int c = tid & ((1 << cw_shift) - 1), rg = tid >> cw_shift, RG = 256 >> cw_shift;
-            if (c < Cs) {
-                // gate-path constants of the tile's (first) cloud: loaded once, re-read only where a tile straddles two clouds
-                int gc_cur = row_gc[0];
-                float g0c = d.gconst[gc_cur + c], g1c = d.gconst[gc_cur + Cs + c];
-                for (int r = rg; r < TE; r += RG) {
-                    const int slot = row_slot[r];
-                    if (slot < 0) continue;
-                    if (row_gc[r] != gc_cur) {
-                        gc_cur = row_gc[r];
-                        g0c = d.gconst[gc_cur + c];
-                        g1c = d.gconst[gc_cur + Cs + c];
-                    }
-                    const float d0 = dxl[r * DXS + c] + g0c;
-                    d.msg[(e0 + r) * R + c] = d0;
-                    const float cen = (dxl[r * DXS + Cs + c] + g1c) - d0;
-                    if (use_lds) atomicAdd(&csl[slot * Cs + c], cen);
-                    else ATOMIC_ADD(&d.ds_acc[(gp_first + slot) * Cs + c], cen);
-                }
-            }
-        }
-        __syncthreads();
-        if (use_lds)
-            for (int i = tid; i < npt * Cs; i += 256) {
-                const float v = csl[i];
-                if (v != 0.f) ATOMIC_ADD(&d.ds_acc[gp_first * Cs + i], v);
-            }
-    }
-
     PHASE_MARK(3);   // phase C1
     // ================= phase C2 (lanes = vector channels, one edge per wave iteration): v2s backward =================
     {
@@ -676,6 +631,12 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
         const uint32_t uCv = (uint32_t)Cv;
         float* const mrow0 = d.msg + ew * R + Cs;   // message row of this wave's first edge (the only 64-bit product)
         float cvd0 = 0.f, cvd1 = 0.f, cvd2 = 0.f;   // centre part of dv (diff lanes carry -sum, centre lanes +sum)
+        const bool s_lane = lane < Cs;
+        const int sl = min(lane, Cs - 1);
+        float cs_sum = 0.f;                          // centre part of ds of the current point (lanes = scalar channels)
+        uint32_t cur_b = (uint32_t)min((int64_t)(ew / ((int64_t)d.N * d.k)), d.B - 1);   // cloud whose gate constants are loaded
+        float g0c = d.gconst[cur_b * 2u * (uint32_t)Cs + sl], g1c = d.gconst[cur_b * 2u * (uint32_t)Cs + Cs + sl];
+        float* const srow0 = d.msg + ew * R;
         float czq = 0.f, czq8 = 0.f;                // centre sums of dL/dz: packed (group g of 8 lanes: entry bitreverse3(g)), entry 8
         const int zq_idx = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2);   // bitreverse3(lane >> 3)
         const bool zq_writer = (lane & 7) == 0;
@@ -689,6 +650,7 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
             ATOMIC_ADD(a_ + uCv, cvd1);                                                                            \
             ATOMIC_ADD(a_ + 2u * uCv, cvd2);                                                                       \
         }                                                                                                         \
+        if (s_lane) ATOMIC_ADD(&d.ds_acc[(p) * (uint32_t)Cs + (uint32_t)lane], cs_sum);                            \
         if (zq_writer) ATOMIC_ADD(&d.dzc[(p) * 9u + (uint32_t)zq_idx], czq);                                       \
         if (lane == 63) ATOMIC_ADD(&d.dzc[(p) * 9u + 8u], czq8);                                                   \
     } while (0)
@@ -715,11 +677,16 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
             const int r = wave * (TE / 4) + rr;
             const EdgeIn& in = q[u];
             // the current edge's point operands are taken BEFORE the requests of this iteration go out (they may re-use `pend`)
-            if (in.valid && in.gp != cur_p) {
+            if (in.in_range && in.gp != cur_p) {
                 if (cur_p != 0xFFFFFFFFu) SVNET_FLUSH_POINT(cur_p);
                 cur_p = in.gp;
                 cvd0 = cvd1 = cvd2 = 0.f;
                 czq = czq8 = 0.f;
+                cs_sum = 0.f;
+                if (in.b != cur_b) {   // the tile straddles two clouds: the other cloud's gate-path constants
+                    cur_b = in.b;
+                    g0c = d.gconst[cur_b * 2u * (uint32_t)Cs + sl]; g1c = d.gconst[cur_b * 2u * (uint32_t)Cs + Cs + sl];
+                }
                 vi0 = pend.vi0; vi1 = pend.vi1; vi2 = pend.vi2;
 #pragma unroll
                 for (int q9 = 0; q9 < 9; ++q9) zc[q9] = pend.zi[(q9 / 3) * 6 + 3 + q9 % 3] - pend.zi[(q9 / 3) * 6 + q9 % 3];
@@ -729,6 +696,13 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
             load_edge(d, cur, __builtin_amdgcn_readlane(jv8, min(rr + 2, TE / 4 - 1)), rr + 2 < TE / 4 ? E : 0, lane, v2_lane, cm,
                       q[(u + 2) & 3], pend, loaded_p);
             const float* row = dxl + r * DXS;
+            if (in.in_range) {   // ---- s part (wave-uniform branch; no load-destination registers inside)
+                const float d0 = row[sl] + g0c;
+                if (s_lane) {
+                    srow0[(uint32_t)rr * (uint32_t)R + lane] = d0;
+                    cs_sum += (row[Cs + sl] + g1c) - d0;
+                }
+            }
             const bool live = v2_lane && in.valid;   // rows past E / dropped edges contribute zeros and store nothing
             const float g0 = live ? row[2 * Cs + lane] : 0.f, g1 = live ? row[2 * Cs + 2 * Cv + lane] : 0.f,
                         g2 = live ? row[2 * Cs + 4 * Cv + lane] : 0.f;
