@@ -370,10 +370,10 @@ __device__ __forceinline__ void load_edge(const svnet_edgeblock_bwd_desc& d, con
     // clamped lane indices: every lane issues every load (no exec-masked branches, loads go out back to back);
     // lanes outside a channel range read a valid neighbour element that is masked where it is consumed
     const uint32_t ld = (uint32_t)min(lane, (int)Cv - 1);
-    const uint32_t oj = in.gj * 3u * Cv + ld;
-    in.vj0 = d.v[oj];
-    in.vj1 = d.v[oj + Cv];
-    in.vj2 = d.v[oj + 2u * Cv];
+    const float* vj = d.v + in.gj * 3u * Cv;        // wave-uniform row base + 32-bit lane byte offsets: SGPR-base loads
+    in.vj0 = ld_f32_sbase(vj, 4u * ld);
+    in.vj1 = ld_f32_sbase(vj, 4u * (ld + Cv));
+    in.vj2 = ld_f32_sbase(vj, 4u * (ld + 2u * Cv));
     const float* zj = d.zz + in.gj * 18u;
     in.zj[0] = zj[0];  in.zj[1] = zj[1];  in.zj[2] = zj[2];
     in.zj[3] = zj[6];  in.zj[4] = zj[7];  in.zj[5] = zj[8];
@@ -640,6 +640,8 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
         float czq = 0.f, czq8 = 0.f;                // centre sums of dL/dz: packed (group g of 8 lanes: entry bitreverse3(g)), entry 8
         const int zq_idx = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2);   // bitreverse3(lane >> 3)
         const bool zq_writer = (lane & 7) == 0;
+        const uint32_t bo_d0 = 4u * (uint32_t)lane, bo_d1 = 4u * (uint32_t)(Cv + lane), bo_d2 = 4u * (uint32_t)(2 * Cv + lane),
+                       bo_zq = 4u * (uint32_t)(3 * Cv + zq_idx), bo_z8 = 4u * (uint32_t)(3 * Cv + 8);   // byte offsets inside a message row
 
 // (a macro: a by-reference lambda forces the per-point accumulators into scratch memory)
 #define SVNET_FLUSH_POINT(p)                                                                                      \
@@ -699,7 +701,7 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
             if (in.in_range) {   // ---- s part (wave-uniform branch; no load-destination registers inside)
                 const float d0 = row[sl] + g0c;
                 if (s_lane) {
-                    srow0[(uint32_t)rr * (uint32_t)R + lane] = d0;
+                    st_f32_sbase(srow0 + (uint32_t)rr * (uint32_t)R, 4u * (uint32_t)lane, d0);
                     cs_sum += (row[Cs + sl] + g1c) - d0;
                 }
             }
@@ -725,10 +727,10 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
             else if (v2_lane) { cvd0 += dve0; cvd1 += dve1; cvd2 += dve2; }
             // ---- the neighbour's share: plain stores into the edge's message row
             if (in.valid) {
-                float* m = mrow0 + (uint32_t)rr * (uint32_t)R;
-                if (diff_lane) { m[lane] = dve0; m[Cv + lane] = dve1; m[2 * Cv + lane] = dve2; }
-                if (zq_writer) m[3 * Cv + zq_idx] = dzp;
-                if (lane == 63) m[3 * Cv + 8] = dz8;
+                float* m = mrow0 + (uint32_t)rr * (uint32_t)R;   // wave-uniform: SGPR-base stores with 32-bit lane byte offsets
+                if (diff_lane) { st_f32_sbase(m, bo_d0, dve0); st_f32_sbase(m, bo_d1, dve1); st_f32_sbase(m, bo_d2, dve2); }
+                if (zq_writer) st_f32_sbase(m, bo_zq, dzp);
+                if (lane == 63) st_f32_sbase(m, bo_z8, dz8);
             }
         }
         }
