@@ -179,8 +179,8 @@ def main():
             per_launch = {"bound": "hbm", "achieved": round(alg / dur / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(alg / dur / 1e9 / HBM_PEAK_GBS, 4),
                           # not measured live: rocprofv3 --pmc passes of this same command, 2 x FETCH_SIZE (gfx950 counts 64 B per
-                          # 128-B request) + WRITE_SIZE, per launch (profiles/r01_v11_pmc_fetch_write_summary.csv)
-                          "traffic": 2 * 148120.8e3 + 864077.7e3, "traffic_source": "profiles/r01_v11_pmc_fetch_write_summary.csv",
+                          # 128-B request) + WRITE_SIZE, per launch (profiles/r01_v12_pmc_fetch_write_summary.csv)
+                          "traffic": 2 * 147664.9e3 + 866907.0e3, "traffic_source": "profiles/r01_v12_pmc_fetch_write_summary.csv",
                           "kernel": "edgeblock_bwd_kernel<0,8> (conv4 backward tile kernel: Cs=64 Cv=21 -> Os=128 Ov=42)",
                           "avg_launch_us": round(dur * 1e6, 1), "algorithmic_bytes": alg,
                           "note": "instruction/latency-bound (64-lane waves carry 21..64 channels), not bandwidth-bound; see DESIGN.md"}
