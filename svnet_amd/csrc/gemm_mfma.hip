@@ -88,9 +88,14 @@ constexpr int KC = 128;         // K chunk staged in LDS
 constexpr int LDS_STRIDE = KC + 8;  // bf16 elements per LDS row: (KC/8 + 1) 16-byte slots, odd -> conflict-free b128 reads
 
 // NT = number of 32-column tiles handled by a workgroup (N_tile = 32*NT <= 256); 4 waves x 32 rows per iteration.
-template <int NT>
+// AVEC: A rows are 16-byte aligned, lda % 4 == 0 and K % 8 == 0 -> every fragment is two unconditional dwordx4 loads (a
+// k-step past K re-reads the row's last 8 values against zero-padded B); otherwise per-element guarded loads.
+template <int NT, bool AVEC>
 __global__ __launch_bounds__(256, 2) void mfma_rows_kernel(RowsArgs a) {
     extern __shared__ __attribute__((aligned(16))) __bf16 Bt[];  // [NT*32][LDS_STRIDE]
+    // per-k scale of the A operand for the current K chunk (ones without a_scale): read through LDS, i.e. counted by lgkmcnt -
+    // a global read per k-step shared vmcnt with the A prefetch and was drained together with it before every MFMA group
+    __shared__ __attribute__((aligned(16))) float ascale_l[KC];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.y * (NT * 32);
@@ -117,14 +122,15 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_kernel(RowsArgs a) {
         float xn[8];
 #define SVNET_LOAD_A(KK)                                                                                      \
     do {                                                                                                      \
-        const int kk_ = (KK);                                                                                 \
-        if (a.a_vec && kk_ + 8 <= a.K) {                                                                      \
+        const int kk_ = AVEC ? min((KK), a.K - 8) : (KK);                                                     \
+        if (AVEC) {                                                                                           \
             const float4 v0_ = *reinterpret_cast<const float4*>(arp + kk_);                                   \
             const float4 v1_ = *reinterpret_cast<const float4*>(arp + kk_ + 4);                               \
             xn[0] = v0_.x; xn[1] = v0_.y; xn[2] = v0_.z; xn[3] = v0_.w;                                       \
             xn[4] = v1_.x; xn[5] = v1_.y; xn[6] = v1_.z; xn[7] = v1_.w;                                       \
         } else {                                                                                              \
-            _Pragma("unroll") for (int j = 0; j < 8; ++j) xn[j] = (kk_ + j < a.K) ? arp[kk_ + j] : 0.f;       \
+            /* clamped, unconditional: columns past K meet zero-padded B rows (and a zero scale) */          \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) xn[j] = arp[min(kk_ + j, a.K - 1)];                 \
         }                                                                                                     \
     } while (0)
         SVNET_LOAD_A(8 * h);
@@ -137,6 +143,7 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_kernel(RowsArgs a) {
                 __syncthreads();  // previous readers of Bt are done
                 // stage B[k0 : k0+kc, n0 : n0+NT*32] as bf16 [n][k]: one 16-byte LDS store per 8 consecutive k
                 const int pieces = NT * 32 * (kc16 >> 3);
+                if (tid < KC) ascale_l[tid] = a.a_scale ? ((k0 + tid < a.K) ? a.a_scale[k0 + tid] : 0.f) : 1.f;
                 if (a.B16) {                  // pre-packed bf16 [n][k]: plain 16-byte copies, all in flight together
                     const int kp = kc16 >> 3;
                     for (int e = tid; e < pieces; e += 256) {
@@ -180,11 +187,13 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_kernel(RowsArgs a) {
                 for (int j = 0; j < 8; ++j) x[j] = xn[j];
                 {   // next fragment: next k-step of this chunk, or the first of the next chunk (none after the last)
                     const int nk = (ks + 16 < kc16) ? kk + 16 : k0 + KC + 8 * h;
-                    if (nk < a.K) SVNET_LOAD_A(nk);
+                    // unconditional (clamped): a branch around the request makes the waitcnt pass drain it before the MFMAs
+                    SVNET_LOAD_A(nk);
                 }
-                if (a.a_scale) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) x[j] *= (kk + j < a.K) ? a.a_scale[kk + j] : 0.f;
+                {
+                    const float4 s0 = *reinterpret_cast<const float4*>(&ascale_l[ks + 8 * h]);
+                    const float4 s1 = *reinterpret_cast<const float4*>(&ascale_l[ks + 8 * h + 4]);
+                    x[0] *= s0.x; x[1] *= s0.y; x[2] *= s0.z; x[3] *= s0.w; x[4] *= s1.x; x[5] *= s1.y; x[6] *= s1.z; x[7] *= s1.w;
                 }
                 const Split3 s = split_frag(x);
 #pragma unroll
@@ -506,8 +515,8 @@ __global__ void zero2d_kernel(float* C, int64_t P, int64_t Q, int64_t ps, int64_
         C[(o / Q) * ps + (o % Q) * qs] = 0.f;
 }
 
-template <int NT>
-void launch_rows(const RowsArgs& a, hipStream_t st) {
+template <int NT, bool AVEC>
+void launch_rows_v(const RowsArgs& a, hipStream_t st) {
     const int64_t row_blocks = svnet_cdiv(a.M, 128);
     const int ny = (int)svnet_cdiv(a.N, NT * 32);
     int64_t gx = row_blocks;
@@ -516,10 +525,14 @@ void launch_rows(const RowsArgs& a, hipStream_t st) {
     const size_t lds = (size_t)NT * 32 * LDS_STRIDE * sizeof(__bf16);
     static bool attr_set = false;  // > 64 KiB of dynamic LDS needs an explicit opt-in (NT = 8: 68 KiB)
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_rows_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_rows_kernel<NT, AVEC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((mfma_rows_kernel<NT>), dim3((unsigned)gx, (unsigned)ny), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((mfma_rows_kernel<NT, AVEC>), dim3((unsigned)gx, (unsigned)ny), dim3(256), lds, st, a);
+}
+template <int NT>
+void launch_rows(const RowsArgs& a, hipStream_t st) {
+    if (a.a_vec && a.K >= 8 && (a.K & 7) == 0) launch_rows_v<NT, true>(a, st); else launch_rows_v<NT, false>(a, st);
 }
 
 template <int NQ, int BMODE>
