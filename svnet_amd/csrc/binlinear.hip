@@ -97,16 +97,18 @@ __global__ __launch_bounds__(256) void binlinear_fwd_kernel(const float* __restr
         {
             int lr = wave, lw = 0;                                   // load cursor (row, first word of the batch)
             constexpr int PB = KWM >= 16 ? 16 : (KWM >= 8 ? 8 : 4);  // wide rows: whole-row batches (these passes are pure latency)
-            float tn[PB];
+            // RAW values are kept (x and beta apart) and the request is unconditional (past the tile's last row it repeats that
+            // row): an add at request time waits for both loads right there, and a branch around the request makes the waitcnt
+            // pass drain it - either way every batch paid a full memory latency
+            float tn[PB], bn[PB];
 #define SVNET_BL_LOAD()                                                                                   \
     do {                                                                                                  \
-        if (lr < rows) {                                                                                  \
-            const float* xr_ = x + (row0 + lr) * ldx;                                                     \
-            _Pragma("unroll") for (int u = 0; u < PB; ++u) {                                              \
-                const int k_ = (lw + u) * 64 + lane;                                                      \
-                const int kc_ = k_ < K ? k_ : K - 1; /* clamped: unconditional loads */                   \
-                tn[u] = xr_[kc_] + beta[kc_];                                                             \
-            }                                                                                             \
+        const float* xr_ = x + (row0 + min(lr, rows - 1)) * ldx;                                          \
+        _Pragma("unroll") for (int u = 0; u < PB; ++u) {                                                  \
+            const int k_ = (lw + u) * 64 + lane;                                                          \
+            const int kc_ = k_ < K ? k_ : K - 1; /* clamped: unconditional loads */                       \
+            tn[u] = xr_[kc_];                                                                             \
+            bn[u] = beta[kc_];                                                                            \
         }                                                                                                 \
     } while (0)
             SVNET_BL_LOAD();
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) void binlinear_fwd_kernel(const float* __restr
             while (r < rows) {
                 float t[PB];
 #pragma unroll
-                for (int u = 0; u < PB; ++u) t[u] = tn[u];
+                for (int u = 0; u < PB; ++u) t[u] = tn[u] + bn[u];
                 lw += PB;
                 if (lw >= KW) { lw = 0; lr += 4; }
                 SVNET_BL_LOAD();
