@@ -25,7 +25,7 @@ _lib.LIB_PATH = os.environ["SVNET_HIP_LIB"]
 from svnet_amd.models.sv_layers import SVBlock
 from svnet_amd.models.utils.sv_util import get_graph_feature_sv, svpool
 config.FUSE_EDGE_BLOCKS = True
-names = ["A", "transpose", "B", "C1", "C2"]
+names = ["A", "transpose", "B", "(C1, merged into C)", "C"]
 for (Cs, Cv, Os, Ov) in [(32, 10, 32, 10), (32, 10, 64, 21), (64, 21, 128, 42)]:
     with contextlib.redirect_stdout(io.StringIO()):
         blk = SVBlock((2 * Cs, 2 * Cv), (Os, Ov), binary=True).cuda().train()
