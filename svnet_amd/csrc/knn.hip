@@ -210,16 +210,22 @@ __device__ __forceinline__ void wave_sort_desc(float& v, int& j, int lane) {
 // STAGE: the four waves of a workgroup share the candidate rows through LDS (CC channels at a time, N % 4 == 0): every wave
 // needs the whole [C, N] table of its cloud, so without sharing the L2 -> CU traffic is 4x what the arithmetic can hide.
 constexpr int KNN_CC = 8;
-template <int T, int Q, bool STAGE>
-__global__ __launch_bounds__(256) void knn_main_kernel(const float* __restrict__ xT, const float* __restrict__ xx,
-                                                       int N, int C, int k, int64_t* __restrict__ idx_out) {
-    __shared__ float cand_v[4 * 64];
-    __shared__ int cand_j[4 * 64];
+// SPLIT (T = 16, Q = 4, N % 16 == 0): in the distance loop the four waves split the CANDIDATES (256 each) and every wave carries
+// all 16 queries of the workgroup, so a channel costs a wave 1 KB of LDS reads instead of 4 KB for the same 32 packed FMAs (the
+// loop was co-limited by LDS bytes); the finished inner products are then handed over through LDS to the layout the selection
+// works on (wave = 4 queries x all candidates).  The fmaf chain of every (query, candidate) pair is unchanged.
+// WPB = waves per workgroup (8 with SPLIT: 32 queries share one pass over the cloud's [C, N] table - every workgroup stages the
+// WHOLE table through LDS, 520 KB at C = 127, so the L2 -> LDS traffic of a call is (N / queries per workgroup) tables per cloud).
+template <int T, int Q, bool STAGE, bool SPLIT = false, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void knn_main_kernel(const float* __restrict__ xT, const float* __restrict__ xx,
+                                                            int N, int C, int k, int64_t* __restrict__ idx_out) {
+    __shared__ float cand_v[WPB * 64];
+    __shared__ int cand_j[WPB * 64];
     extern __shared__ __attribute__((aligned(16))) float rows[];      // STAGE: [KNN_CC][64 * T]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int b = blockIdx.y;
-    const int q0 = (blockIdx.x * 4 + wave) * Q;
+    const int q0 = (blockIdx.x * WPB + wave) * Q;
     if (!STAGE && q0 >= N) return;  // wave-uniform (no workgroup barriers in the unstaged variant: the LDS slices are per wave)
 
     const float* __restrict__ xb = xT + (size_t)b * C * N;
@@ -234,17 +240,19 @@ __global__ __launch_bounds__(256) void knn_main_kernel(const float* __restrict__
     int qi[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) qi[q] = min(q0 + q, N - 1);
+    float (&accs)[Q][T] = acc;                                       // SPLIT: the same 64 registers, indexed [q % 4][(q / 4) * T/4 + t]
 
     if (STAGE) {
         // chunk i+1 travels global -> registers while chunk i is consumed from LDS; the FMA chain over c keeps its order
         constexpr int NP = 64 * T;
-        constexpr int F4 = (KNN_CC * NP / 4 / 256) > 0 ? (KNN_CC * NP / 4 / 256) : 1;   // float4 per thread per chunk (STAGE needs T >= 4)
+        constexpr int NTH = 64 * WPB;
+        constexpr int F4 = (KNN_CC * NP / 4 / NTH) > 0 ? (KNN_CC * NP / 4 / NTH) : 1;   // float4 per thread per chunk (STAGE needs T >= 4)
         float4 stg[F4];
         const int n4 = N >> 2;
 #define SVNET_KNN_FETCH(C0)                                                                         \
     do {                                                                                            \
         _Pragma("unroll") for (int u = 0; u < F4; ++u) {                                            \
-            const int e_ = u * 256 + threadIdx.x;                                                   \
+            const int e_ = u * NTH + threadIdx.x;                                                   \
             const int rw_ = e_ / (NP / 4), c4_ = e_ - rw_ * (NP / 4);                               \
             stg[u] = ((C0) + rw_ < C && c4_ < n4) ? *reinterpret_cast<const float4*>(xb + (size_t)((C0) + rw_) * N + 4 * c4_) \
                                                    : make_float4(0.f, 0.f, 0.f, 0.f);               \
@@ -254,10 +262,30 @@ __global__ __launch_bounds__(256) void knn_main_kernel(const float* __restrict__
         for (int c0 = 0; c0 < C; c0 += KNN_CC) {
             __syncthreads();                                         // the previous chunk has been consumed
 #pragma unroll
-            for (int u = 0; u < F4; ++u) *reinterpret_cast<float4*>(&rows[4 * (u * 256 + threadIdx.x)]) = stg[u];
+            for (int u = 0; u < F4; ++u) *reinterpret_cast<float4*>(&rows[4 * (u * NTH + threadIdx.x)]) = stg[u];
             __syncthreads();
             if (c0 + KNN_CC < C) SVNET_KNN_FETCH(c0 + KNN_CC);
             const int cc_end = min(KNN_CC, C - c0);
+            if (SPLIT) {
+                constexpr int TS = T / WPB > 0 ? T / WPB : 1, QB = WPB * Q;   // candidates per lane, queries per workgroup
+                const int qb0 = blockIdx.x * QB;                      // N % QB == 0: the workgroup's queries all exist, 16-byte aligned
+                for (int cc = 0; cc < cc_end; ++cc) {
+                    const float* row = rows + cc * NP;
+                    float cand[TS], qv[QB];
+#pragma unroll
+                    for (int t = 0; t < TS; ++t) cand[t] = row[64 * TS * wave + lane + 64 * t];
+#pragma unroll
+                    for (int i = 0; i < QB / 4; ++i) {
+                        const float4 q4 = *reinterpret_cast<const float4*>(row + qb0 + 4 * i);   // broadcast read
+                        qv[4 * i] = q4.x; qv[4 * i + 1] = q4.y; qv[4 * i + 2] = q4.z; qv[4 * i + 3] = q4.w;
+                    }
+#pragma unroll
+                    for (int q = 0; q < QB; ++q)
+#pragma unroll
+                        for (int t = 0; t < TS; ++t) accs[(q * TS + t) / T][(q * TS + t) % T] = __builtin_fmaf(qv[q], cand[t], accs[(q * TS + t) / T][(q * TS + t) % T]);
+                }
+                continue;
+            }
             for (int cc = 0; cc < cc_end; ++cc) {
                 const float* row = rows + cc * NP;
                 float cand[T], qv[Q];
@@ -272,6 +300,33 @@ __global__ __launch_bounds__(256) void knn_main_kernel(const float* __restrict__
             }
         }
 #undef SVNET_KNN_FETCH
+        if (SPLIT) {
+            // accs (the 64 registers of acc, flat index q * TS + t) = inner product of query qb0 + q with candidate 64 * TS * wave + 64 * t + lane.
+            // Hand-over in passes of 8 queries (8 x 1024 floats = the staging buffer's 32 KB): the two waves that own them read.
+            constexpr int TS = T / WPB > 0 ? T / WPB : 1, QB = WPB * Q;
+            float mine[Q][T];
+#pragma unroll
+            for (int pass = 0; pass < QB / 8; ++pass) {
+                __syncthreads();                                     // rows[] is free (last chunk consumed / previous pass read)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int qq = pass * 8 + q;
+#pragma unroll
+                    for (int t = 0; t < TS; ++t) rows[q * NP + 64 * TS * wave + 64 * t + lane] = accs[(qq * TS + t) / T][(qq * TS + t) % T];
+                }
+                __syncthreads();
+                if ((wave >> 1) == pass) {                           // waves 2*pass, 2*pass+1 own queries 8*pass .. 8*pass+7 (Q = 4)
+#pragma unroll
+                    for (int q = 0; q < Q; ++q)
+#pragma unroll
+                        for (int t = 0; t < T; ++t) mine[q][t] = rows[((wave & 1) * Q + q) * NP + 64 * t + lane];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+#pragma unroll
+                for (int t = 0; t < T; ++t) acc[q][t] = mine[q][t];
+        }
         if (q0 >= N) return;                                         // idle waves only helped with the staging
     } else {
     // channel c+1's candidate row and query values are requested before channel c's FMAs (the chain over c is what fixes
@@ -379,7 +434,11 @@ template <int T, int Q>
 void launch_main(const float* xT, const float* xx, int64_t B, int N, int C, int k, int64_t* idx, hipStream_t st) {
     dim3 grid((unsigned)svnet_cdiv(N, 4 * Q), (unsigned)B);
     constexpr size_t stage_bytes = (size_t)KNN_CC * 64 * T * sizeof(float);
-    if (T >= 4 && T <= 16 && (N & 3) == 0 && C >= 8)       // (T < 4: the staging chunk would not fill the 256 threads' float4 slots)
+    // (WPB = 8 - 32 queries per pass over the cloud's table - was measured: 521 us against 425 for the three feature-space graphs of
+    //  the bench; one 8-wave workgroup per CU loses more to its barriers than it saves in staging traffic)
+    if (T == 16 && Q == 4 && (N & 15) == 0 && C >= 8)
+        hipLaunchKernelGGL((knn_main_kernel<T, Q, (T >= 4 && T <= 16), (T == 16 && Q == 4), 4>), grid, dim3(256), stage_bytes, st, xT, xx, N, C, k, idx);
+    else if (T >= 4 && T <= 16 && (N & 3) == 0 && C >= 8)       // (T < 4: the staging chunk would not fill the 256 threads' float4 slots)
         hipLaunchKernelGGL((knn_main_kernel<T, Q, (T >= 4 && T <= 16)>), grid, dim3(256), stage_bytes, st, xT, xx, N, C, k, idx);
     else
         hipLaunchKernelGGL((knn_main_kernel<T, Q, false>), grid, dim3(256), 0, st, xT, xx, N, C, k, idx);
