@@ -218,14 +218,22 @@ constexpr int KNN_CC = 8;
 // WHOLE table through LDS, 520 KB at C = 127, so the L2 -> LDS traffic of a call is (N / queries per workgroup) tables per cloud).
 template <int T, int Q, bool STAGE, bool SPLIT = false, int WPB = 4>
 __global__ __launch_bounds__(64 * WPB) void knn_main_kernel(const float* __restrict__ xT, const float* __restrict__ xx,
-                                                            int N, int C, int k, int64_t* __restrict__ idx_out) {
+                                                            int N, int C, int k, int64_t* __restrict__ idx_out, int xcd_blocks_per_cloud) {
     __shared__ float cand_v[WPB * 64];
     __shared__ int cand_j[WPB * 64];
     extern __shared__ __attribute__((aligned(16))) float rows[];      // STAGE: [KNN_CC][64 * T]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int b = blockIdx.y;
-    const int q0 = (blockIdx.x * WPB + wave) * Q;
+    // XCD-aware order (workgroups w and w+8 share an XCD): with B % 8 == 0 the launch is one-dimensional and XCD x walks the clouds
+    // x, x+8, ... one after the other, so the cloud's [C, N] table - which EVERY workgroup of the cloud reads in full - is served
+    // by one XCD's L2 instead of being resident in all eight
+    int bx = blockIdx.x, b = blockIdx.y;
+    if (gridDim.y == 1 && xcd_blocks_per_cloud > 0) {
+        const int w = blockIdx.x, per = xcd_blocks_per_cloud;
+        b = (w / (per * 8)) * 8 + (w & 7);
+        bx = (w >> 3) % per;
+    }
+    const int q0 = (bx * WPB + wave) * Q;
     if (!STAGE && q0 >= N) return;  // wave-uniform (no workgroup barriers in the unstaged variant: the LDS slices are per wave)
 
     const float* __restrict__ xb = xT + (size_t)b * C * N;
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(64 * WPB) void knn_main_kernel(const float* __restr
             const int cc_end = min(KNN_CC, C - c0);
             if (SPLIT) {
                 constexpr int TS = T / WPB > 0 ? T / WPB : 1, QB = WPB * Q;   // candidates per lane, queries per workgroup
-                const int qb0 = blockIdx.x * QB;                      // N % QB == 0: the workgroup's queries all exist, 16-byte aligned
+                const int qb0 = bx * QB;                              // N % QB == 0: the workgroup's queries all exist, 16-byte aligned
                 for (int cc = 0; cc < cc_end; ++cc) {
                     const float* row = rows + cc * NP;
                     float cand[TS], qv[QB];
@@ -433,15 +441,17 @@ __global__ __launch_bounds__(64 * WPB) void knn_main_kernel(const float* __restr
 template <int T, int Q>
 void launch_main(const float* xT, const float* xx, int64_t B, int N, int C, int k, int64_t* idx, hipStream_t st) {
     dim3 grid((unsigned)svnet_cdiv(N, 4 * Q), (unsigned)B);
+    int per = 0;
+    if ((B & 7) == 0) { per = (int)grid.x; grid = dim3((unsigned)(grid.x * B), 1u); }   // XCD-aware cloud order (see the kernel)
     constexpr size_t stage_bytes = (size_t)KNN_CC * 64 * T * sizeof(float);
     // (WPB = 8 - 32 queries per pass over the cloud's table - was measured: 521 us against 425 for the three feature-space graphs of
     //  the bench; one 8-wave workgroup per CU loses more to its barriers than it saves in staging traffic)
     if (T == 16 && Q == 4 && (N & 15) == 0 && C >= 8)
-        hipLaunchKernelGGL((knn_main_kernel<T, Q, (T >= 4 && T <= 16), (T == 16 && Q == 4), 4>), grid, dim3(256), stage_bytes, st, xT, xx, N, C, k, idx);
+        hipLaunchKernelGGL((knn_main_kernel<T, Q, (T >= 4 && T <= 16), (T == 16 && Q == 4), 4>), grid, dim3(256), stage_bytes, st, xT, xx, N, C, k, idx, per);
     else if (T >= 4 && T <= 16 && (N & 3) == 0 && C >= 8)       // (T < 4: the staging chunk would not fill the 256 threads' float4 slots)
-        hipLaunchKernelGGL((knn_main_kernel<T, Q, (T >= 4 && T <= 16)>), grid, dim3(256), stage_bytes, st, xT, xx, N, C, k, idx);
+        hipLaunchKernelGGL((knn_main_kernel<T, Q, (T >= 4 && T <= 16)>), grid, dim3(256), stage_bytes, st, xT, xx, N, C, k, idx, per);
     else
-        hipLaunchKernelGGL((knn_main_kernel<T, Q, false>), grid, dim3(256), 0, st, xT, xx, N, C, k, idx);
+        hipLaunchKernelGGL((knn_main_kernel<T, Q, false>), grid, dim3(256), 0, st, xT, xx, N, C, k, idx, per);
 }
 
 }  // namespace
