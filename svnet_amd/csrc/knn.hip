@@ -216,7 +216,10 @@ constexpr int KNN_CC = 8;
 // works on (wave = 4 queries x all candidates).  The fmaf chain of every (query, candidate) pair is unchanged.
 // WPB = waves per workgroup (8 with SPLIT: 32 queries share one pass over the cloud's [C, N] table - every workgroup stages the
 // WHOLE table through LDS, 520 KB at C = 127, so the L2 -> LDS traffic of a call is (N / queries per workgroup) tables per cloud).
-template <int T, int Q, bool STAGE, bool SPLIT = false, int WPB = 4>
+// DIRECT (with SPLIT): no staging of the candidates at all - a wave needs only ITS 64*T/WPB candidates of a channel (four coalesced
+// 256-byte loads), so it takes them from L2 into a four-channel register ring; only the workgroup's 16 query rows go through LDS
+// (once).  No barrier inside the channel loop.
+template <int T, int Q, bool STAGE, bool SPLIT = false, int WPB = 4, bool DIRECT = false>
 __global__ __launch_bounds__(64 * WPB) void knn_main_kernel(const float* __restrict__ xT, const float* __restrict__ xx,
                                                             int N, int C, int k, int64_t* __restrict__ idx_out, int xcd_blocks_per_cloud) {
     __shared__ float cand_v[WPB * 64];
@@ -266,6 +269,46 @@ __global__ __launch_bounds__(64 * WPB) void knn_main_kernel(const float* __restr
                                                    : make_float4(0.f, 0.f, 0.f, 0.f);               \
         }                                                                                           \
     } while (0)
+        if (SPLIT && DIRECT) {
+            constexpr int TS = T / WPB > 0 ? T / WPB : 1, QB = WPB * Q;
+            const int qb0 = bx * QB;
+            const int C4 = (C + 3) & ~3;
+            for (int e = threadIdx.x; e < C4 * QB; e += NTH) {          // rows[c * QB + i] = x[c][qb0 + i]; channels past C are zeros
+                const int c = e / QB, i = e - c * QB;
+                rows[e] = c < C ? xb[(size_t)c * N + qb0 + i] : 0.f;
+            }
+            int joff[TS];
+#pragma unroll
+            for (int t = 0; t < TS; ++t) joff[t] = min(64 * TS * wave + 64 * t + lane, N - 1);
+            float cn[4][TS];
+#define SVNET_KNN_LOADC(SLOT, CH)                                                                   \
+    do {                                                                                            \
+        const float* r_ = xb + (size_t)min((CH), C - 1) * N;                                        \
+        _Pragma("unroll") for (int t = 0; t < TS; ++t) cn[SLOT][t] = r_[joff[t]];                   \
+    } while (0)
+            SVNET_KNN_LOADC(0, 0); SVNET_KNN_LOADC(1, 1); SVNET_KNN_LOADC(2, 2);
+            __syncthreads();
+            for (int c4 = 0; c4 < C4; c4 += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = c4 + u;
+                    SVNET_KNN_LOADC((u + 3) & 3, c + 3);               // unconditional, clamped: three channels ahead
+                    __builtin_amdgcn_sched_barrier(0);
+                    float qv[QB];
+#pragma unroll
+                    for (int i = 0; i < QB / 4; ++i) {
+                        const float4 q4 = *reinterpret_cast<const float4*>(rows + c * QB + 4 * i);   // broadcast read (zeros past C)
+                        qv[4 * i] = q4.x; qv[4 * i + 1] = q4.y; qv[4 * i + 2] = q4.z; qv[4 * i + 3] = q4.w;
+                    }
+#pragma unroll
+                    for (int q = 0; q < QB; ++q)
+#pragma unroll
+                        for (int t = 0; t < TS; ++t)
+                            accs[(q * TS + t) / T][(q * TS + t) % T] = __builtin_fmaf(qv[q], cn[u][t], accs[(q * TS + t) / T][(q * TS + t) % T]);
+                }
+            }
+#undef SVNET_KNN_LOADC
+        } else {
         SVNET_KNN_FETCH(0);
         for (int c0 = 0; c0 < C; c0 += KNN_CC) {
             __syncthreads();                                         // the previous chunk has been consumed
@@ -306,6 +349,7 @@ __global__ __launch_bounds__(64 * WPB) void knn_main_kernel(const float* __restr
 #pragma unroll
                     for (int t = 0; t < T; ++t) acc[q][t] = __builtin_fmaf(qv[q], cand[t], acc[q][t]);
             }
+        }
         }
 #undef SVNET_KNN_FETCH
         if (SPLIT) {
@@ -447,7 +491,7 @@ void launch_main(const float* xT, const float* xx, int64_t B, int N, int C, int 
     // (WPB = 8 - 32 queries per pass over the cloud's table - was measured: 521 us against 425 for the three feature-space graphs of
     //  the bench; one 8-wave workgroup per CU loses more to its barriers than it saves in staging traffic)
     if (T == 16 && Q == 4 && (N & 15) == 0 && C >= 8)
-        hipLaunchKernelGGL((knn_main_kernel<T, Q, (T >= 4 && T <= 16), (T == 16 && Q == 4), 4>), grid, dim3(256), stage_bytes, st, xT, xx, N, C, k, idx, per);
+        hipLaunchKernelGGL((knn_main_kernel<T, Q, (T >= 4 && T <= 16), (T == 16 && Q == 4), 4, true>), grid, dim3(256), stage_bytes, st, xT, xx, N, C, k, idx, per);
     else if (T >= 4 && T <= 16 && (N & 3) == 0 && C >= 8)       // (T < 4: the staging chunk would not fill the 256 threads' float4 slots)
         hipLaunchKernelGGL((knn_main_kernel<T, Q, (T >= 4 && T <= 16)>), grid, dim3(256), stage_bytes, st, xT, xx, N, C, k, idx, per);
     else
