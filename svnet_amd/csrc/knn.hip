@@ -490,7 +490,7 @@ void launch_main(const float* xT, const float* xx, int64_t B, int N, int C, int 
     constexpr size_t stage_bytes = (size_t)KNN_CC * 64 * T * sizeof(float);
     // (WPB = 8 - 32 queries per pass over the cloud's table - was measured: 521 us against 425 for the three feature-space graphs of
     //  the bench; one 8-wave workgroup per CU loses more to its barriers than it saves in staging traffic)
-    if (T == 16 && Q == 4 && (N & 15) == 0 && C >= 8)
+    if (T == 16 && Q == 4 && (N & 15) == 0)               // (any C: the direct form stages nothing)
         hipLaunchKernelGGL((knn_main_kernel<T, Q, (T >= 4 && T <= 16), (T == 16 && Q == 4), 4, true>), grid, dim3(256), stage_bytes, st, xT, xx, N, C, k, idx, per);
     else if (T >= 4 && T <= 16 && (N & 3) == 0 && C >= 8)       // (T < 4: the staging chunk would not fill the 256 threads' float4 slots)
         hipLaunchKernelGGL((knn_main_kernel<T, Q, (T >= 4 && T <= 16)>), grid, dim3(256), stage_bytes, st, xT, xx, N, C, k, idx, per);
