@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64 * WPB) void knn_main_kernel(const float* __restr
     for (int q = 0; q < Q; ++q) qi[q] = min(q0 + q, N - 1);
     float (&accs)[Q][T] = acc;                                       // SPLIT: the same 64 registers, indexed [q % 4][(q / 4) * T/4 + t]
 
-    if (STAGE) {
+    if (STAGE || (SPLIT && DIRECT)) {
         // chunk i+1 travels global -> registers while chunk i is consumed from LDS; the FMA chain over c keeps its order
         constexpr int NP = 64 * T;
         constexpr int NTH = 64 * WPB;
@@ -353,25 +353,26 @@ __global__ __launch_bounds__(64 * WPB) void knn_main_kernel(const float* __restr
         }
 #undef SVNET_KNN_FETCH
         if (SPLIT) {
-            // accs (the 64 registers of acc, flat index q * TS + t) = inner product of query qb0 + q with candidate 64 * TS * wave + 64 * t + lane.
-            // Hand-over in passes of 8 queries (8 x 1024 floats = the staging buffer's 32 KB): the two waves that own them read.
+            // accs (the registers of acc, flat index q * TS + t) = inner product of query qb0 + q with candidate 64 * TS * wave + 64 * t + lane.
+            // Hand-over in passes of PQ queries (PQ x 64T floats = 32 KB of LDS): the waves that own them read.
             constexpr int TS = T / WPB > 0 ? T / WPB : 1, QB = WPB * Q;
+            constexpr int PQ = (8192 / NP) > 0 ? (8192 / NP) : 1;      // 8 at N <= 1024, 4 at N <= 2048
             float mine[Q][T];
 #pragma unroll
-            for (int pass = 0; pass < QB / 8; ++pass) {
+            for (int pass = 0; pass < QB / PQ; ++pass) {
                 __syncthreads();                                     // rows[] is free (last chunk consumed / previous pass read)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int qq = pass * 8 + q;
+                for (int q = 0; q < PQ; ++q) {
+                    const int qq = pass * PQ + q;
 #pragma unroll
                     for (int t = 0; t < TS; ++t) rows[q * NP + 64 * TS * wave + 64 * t + lane] = accs[(qq * TS + t) / T][(qq * TS + t) % T];
                 }
                 __syncthreads();
-                if ((wave >> 1) == pass) {                           // waves 2*pass, 2*pass+1 own queries 8*pass .. 8*pass+7 (Q = 4)
+                if ((wave * Q) / PQ == pass) {                       // the waves whose Q queries lie in this pass
 #pragma unroll
                     for (int q = 0; q < Q; ++q)
 #pragma unroll
-                        for (int t = 0; t < T; ++t) mine[q][t] = rows[((wave & 1) * Q + q) * NP + 64 * t + lane];
+                        for (int t = 0; t < T; ++t) mine[q][t] = rows[((wave * Q) % PQ + q) * NP + 64 * t + lane];
                 }
             }
 #pragma unroll
@@ -490,8 +491,9 @@ void launch_main(const float* xT, const float* xx, int64_t B, int N, int C, int 
     constexpr size_t stage_bytes = (size_t)KNN_CC * 64 * T * sizeof(float);
     // (WPB = 8 - 32 queries per pass over the cloud's table - was measured: 521 us against 425 for the three feature-space graphs of
     //  the bench; one 8-wave workgroup per CU loses more to its barriers than it saves in staging traffic)
-    if (T == 16 && Q == 4 && (N & 15) == 0)               // (any C: the direct form stages nothing)
-        hipLaunchKernelGGL((knn_main_kernel<T, Q, (T >= 4 && T <= 16), (T == 16 && Q == 4), 4, true>), grid, dim3(256), stage_bytes, st, xT, xx, N, C, k, idx, per);
+    if ((T == 16 || T == 32) && Q == 4 && (N & 15) == 0)   // (any C: the direct form stages nothing; 32 KB of LDS for the hand-over)
+        hipLaunchKernelGGL((knn_main_kernel<T, Q, (T >= 4 && T <= 16), ((T == 16 || T == 32) && Q == 4), 4, true>), grid, dim3(256),
+                           (size_t)32768, st, xT, xx, N, C, k, idx, per);
     else if (T >= 4 && T <= 16 && (N & 3) == 0 && C >= 8)       // (T < 4: the staging chunk would not fill the 256 threads' float4 slots)
         hipLaunchKernelGGL((knn_main_kernel<T, Q, (T >= 4 && T <= 16)>), grid, dim3(256), stage_bytes, st, xT, xx, N, C, k, idx, per);
     else
