@@ -71,8 +71,12 @@ __global__ __launch_bounds__(256) void binlinear_fwd_kernel(const float* __restr
     const int ob = (int)(blockIdx.x % o_blocks);
     o_base += ob * OG;
 
-    // my output channels' weight words (registers for the whole kernel)
-    uint64_t wsg[PPM][KWM], wnz[PPM][KWM];
+    // my output channels' weight words (registers for the whole kernel).  WIDE (KWM > 16, i.e. K > 1024): 2 x 34 words per
+    // thread were 270 VGPRs = one wave per SIMD; there the loops are turned inside out instead (word outermost, one weight word
+    // pair from L2 per step, 64 row counters in registers: ~110 VGPRs)
+    constexpr bool WIDE = KWM > 16;
+    constexpr int KWR = WIDE ? 1 : KWM;
+    uint64_t wsg[PPM][KWR], wnz[PPM][KWR];
     float sc[PPM], bs[PPM];
 #pragma unroll
     for (int p = 0; p < PPM; ++p) {
@@ -80,11 +84,13 @@ __global__ __launch_bounds__(256) void binlinear_fwd_kernel(const float* __restr
         const bool ok = (o < O);
         sc[p] = ok ? scale[o] : 0.f;
         bs[p] = (ok && bias) ? bias[o] : 0.f;
+        if (!WIDE) {
 #pragma unroll
-        for (int w = 0; w < KWM; ++w) {
-            const bool okw = ok && (w < KW);
-            wsg[p][w] = okw ? w_sign[(size_t)o * KW + w] : 0ull;
-            wnz[p][w] = okw ? w_nz[(size_t)o * KW + w] : 0ull;
+            for (int w = 0; w < KWR; ++w) {
+                const bool okw = ok && (w < KW);
+                wsg[p][w] = okw ? w_sign[(size_t)o * KW + w] : 0ull;
+                wnz[p][w] = okw ? w_nz[(size_t)o * KW + w] : 0ull;
+            }
         }
     }
 
@@ -160,6 +166,42 @@ __global__ __launch_bounds__(256) void binlinear_fwd_kernel(const float* __restr
             }
         }
         // ---- phase 2: popcount dot products
+        if (WIDE && og_shift < 8) {
+            // small M (the classifier head: a few row tiles, 32 channels per workgroup, 8 threads per channel take different rows):
+            // weight words straight from L2, one row at a time
+            const int o = min(o_base + o_in, O - 1);
+            for (int r = sub; r < rows; r += nsub) {
+                int cnt = 0;
+                for (int w = 0; w < KW; ++w) {
+                    const uint64_t m = lz[r * KW + w] & w_nz[(size_t)o * KW + w];
+                    cnt += __popcll(m) - 2 * __popcll(m & (ls[r * KW + w] ^ w_sign[(size_t)o * KW + w]));
+                }
+                if (o_base + o_in < O) y[(row0 + r) * O + o] = (float)cnt * sc[0] + bs[0];
+            }
+        } else if (WIDE) {
+            // (PPM = 1, og_shift = 8: thread = output channel, every thread walks all ROWS rows)
+            const int o = min(o_base + o_in, O - 1);
+            int cnt[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) cnt[r] = 0;
+            uint64_t ws_n = w_sign[(size_t)o * KW], wz_n = w_nz[(size_t)o * KW];
+            for (int w = 0; w < KW; ++w) {
+                const uint64_t ws = ws_n, wz = wz_n;
+                const int wn = min(w + 1, KW - 1);                     // next word pair (unconditional, clamped)
+                ws_n = w_sign[(size_t)o * KW + wn]; wz_n = w_nz[(size_t)o * KW + wn];
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const uint64_t xs = ls[r * KW + w], xz = lz[r * KW + w];   // wave-uniform addresses: broadcast reads
+                    const uint64_t m = xz & wz;
+                    cnt[r] += __popcll(m) - 2 * __popcll(m & (xs ^ ws));
+                }
+            }
+            if (o_base + o_in < O) {
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r)
+                    if (r < rows) y[(row0 + r) * O + o] = (float)cnt[r] * sc[0] + bs[0];
+            }
+        } else
         if (o_base + o_in < O) {
             for (int r = sub; r < rows; r += nsub) {
                 int cnt[PPM];
