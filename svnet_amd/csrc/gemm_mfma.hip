@@ -629,7 +629,7 @@ int svnet_mfma_tn(const float* A, int64_t lda, const float* B, int64_t ldb, cons
     else if (Q <= 64) { if (tern) launch_tn<2, 1>(a, st); else launch_tn<2, 0>(a, st); }
     else if (Q <= 128) { if (tern) launch_tn<4, 1>(a, st); else launch_tn<4, 0>(a, st); }
     else if (Q <= 160 || Q == 320) { if (tern) launch_tn<5, 1>(a, st); else launch_tn<5, 0>(a, st); }   // 320 = fused edge block
-    else { if (tern) launch_tn<8, 1>(a, st); else launch_tn<4, 0>(a, st); }   // fp32 B: 128-column groups (register budget of the prefetch)
+    else { if (tern) launch_tn<5, 1>(a, st); else launch_tn<4, 0>(a, st); }   // ternary: 160-column groups too - the 5-tile kernel keeps a whole block of A and the next plane words in flight (8 tiles: 255 VGPRs, neither), worth more than the extra L2 reads of A (conv5: -60 us per step)   // fp32 B: 128-column groups (register budget of the prefetch)
     SVNET_CHECK_LAUNCH("mfma_tn_kernel");
     return SVNET_OK;
 }
