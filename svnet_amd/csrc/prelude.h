@@ -30,8 +30,24 @@ __device__ __forceinline__ void svnet_prelude_body(const float* __restrict__ gs,
         if (o < Os) {
             const float a = A1[o], bb = B1[o], sc = scale1 ? scale1[o] : 1.f, my = MY[o], iy = IY[o];
             float r1 = 0.f, r2 = 0.f;
-            for (int64_t p = p0 + rg; p < p1; p += RG) {
-                const float sel = (float)(a >= 0.f ? sel_max[p * Os + o] : sel_min[p * Os + o]);
+            const SelT* __restrict__ selp = a >= 0.f ? sel_max : sel_min;
+            int64_t p = p0 + rg;
+            // eight rows' loads in flight per thread (one row at a time was a memory latency per row: 32 in a row at Os = 128)
+            for (; p + 7 * RG < p1; p += 8 * RG) {
+                float sv[8], gv8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { sv[u] = (float)selp[(p + u * RG) * Os + o]; gv8[u] = gs[(p + u * RG) * Os + o]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float y = a * sv[u] + bb;
+                    const float g = gv8[u] * (y > 0.f ? 1.f : slope);
+                    gy[(p + u * RG) * Os + o] = g;
+                    r1 += g;
+                    r2 += g * (sc * sv[u] - my) * iy;
+                }
+            }
+            for (; p < p1; p += RG) {
+                const float sel = (float)selp[p * Os + o];
                 const float y = a * sel + bb;
                 const float g = gs[p * Os + o] * (y > 0.f ? 1.f : slope);
                 gy[p * Os + o] = g;
@@ -49,7 +65,26 @@ __device__ __forceinline__ void svnet_prelude_body(const float* __restrict__ gs,
         if (c < Ov) {
             const float av = Av[c], bv = Bv[c], gt = gate[b * Ov + c];
             float ra = 0.f, rb = 0.f, gsum = 0.f;
-            for (int64_t p = p0 + rg; p < p1; p += RG) {
+            int64_t p = p0 + rg;
+            for (; p + 3 * RG < p1; p += 4 * RG) {                   // four rows = 36 loads in flight
+                float g4[4][3], a4[4][3], n4[4][3];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        const int64_t q = ((p + u * RG) * 3 + d) * Ov + c;
+                        g4[u][d] = gv[q]; a4[u][d] = mv[q]; n4[u][d] = mvn[q];
+                    }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        gsum += g4[u][d] * (av * a4[u][d] + bv * n4[u][d]);
+                        ra += g4[u][d] * gt * a4[u][d];
+                        rb += g4[u][d] * gt * n4[u][d];
+                    }
+            }
+            for (; p < p1; p += RG) {
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
                     const int64_t q = (p * 3 + d) * Ov + c;
