@@ -59,6 +59,11 @@ def parse_args():
                     help="which BASELINE.json config to run (default: the headline one, sv_dgcnn_cls --binary B=32 N=1024 k=20)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="default workload only: skip the other BASELINE configs' legs (other_workloads) and the train-loop leg")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="--gpus 1 only: run the RCCL all-reduce(avg) of the real gradient bucket inside the timed loop at world size 1 "
+                         "(the collective's fixed cost on this box: collective_us)")
     return ap.parse_args()
 
 
@@ -403,32 +408,17 @@ def other_workload_legs(args, wl, model, inputs, train, work, torch, _lib):
     return primary, stages
 
 
-def main():
-    args = parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
-        sys.exit(2)
-    wl = WORKLOADS[args.workload]
-    B, N, k = wl["B"], wl["N"], wl["k"]
-
+def build_workload(name, dev, rank=0, B=None):
+    """(wl, model, inputs, target, loss_fn) of one BASELINE.json config: random-init weights of that architecture (manual_seed(0)),
+    rank-indexed synthetic clouds / labels resident on `dev`."""
     import torch
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-
     import svnet_amd.models as M
-    from svnet_amd import _lib, config, synth
-    from svnet_amd.train import ForwardStep, TrainStep, cal_loss, seg_loss
-    _lib.lib()                                                        # fail loudly if the HIP library is missing
-
+    from svnet_amd import synth
+    from svnet_amd.train import cal_loss, seg_loss
+    wl = dict(WORKLOADS[name])
+    if B is not None:
+        wl["B"] = int(B)
+    B, N, k = wl["B"], wl["N"], wl["k"]
     torch.manual_seed(0)
     cls, nc = {"sv_dgcnn_cls": (M.SV_DGCNN_CLS, 40), "sv_pointnet_cls": (M.SV_PointNet_CLS, 40), "sv_dgcnn_pseg": (M.SV_DGCNN_PSEG, 50)}[wl["model"]]
     with contextlib.redirect_stdout(io.StringIO()):
@@ -442,6 +432,113 @@ def main():
         inputs = (x,)
         y = torch.from_numpy(synth.class_labels(1234, 0, rank, B)).to(dev)
         loss_fn = cal_loss
+    return wl, model, inputs, y, loss_fn
+
+
+def other_workloads_leg(args, dev, torch, _lib, steps=10):
+    """BASELINE.json configs 1 / 2 / 5's per-GPU workloads next to the headline line: capture + `steps` replays each,
+    no CPU leg.  {name: {ms_per_step, value, graph_nodes, roofline, ...}}; a workload that fails reports its error instead."""
+    from svnet_amd.train import TrainStep
+    import gc
+    out = {}
+    for name in ("pointnet_fp", "pointnet_bin", "partseg"):
+        try:
+            wl, model, inputs, y, loss_fn = build_workload(name, dev)
+            step = TrainStep(model.train(), inputs, y, loss_fn)
+            step.capture()
+            for _ in range(2):
+                step.run(all_reduce=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step.run(all_reduce=False)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            loss = float(step.loss)
+            sub = argparse.Namespace(mode="train")
+            primary, stages = other_workload_legs(sub, wl, model, inputs, step, step, torch, _lib)
+            nodes = graph_kernel_nodes(step)
+            out[name] = {"workload": "%s fwd+loss+bwd, B=%d N=%d k=%d" % (wl["name"], wl["B"], wl["N"], wl["k"]),
+                         "ms_per_step": round(dt / steps * 1e3, 3), "value": round(wl["B"] * steps / dt, 2), "unit": "point-clouds/sec",
+                         "steps": steps, "launch": "hipGraph replay", "graph_nodes": nodes, "loss_finite": bool(loss == loss and abs(loss) < 1e6),
+                         "roofline": primary, "roofline_stages": stages}
+            del step, model, inputs, y
+        except Exception as e:                                        # a secondary leg must not take the headline line down
+            out[name] = {"error": repr(e)[:300]}
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
+def train_loop_leg(model, inputs, y, loss_fn, torch, steps=20):
+    """What a TRAINING step costs beyond the timed fwd+loss+bwd replay: the flat Adam step (one kernel over
+    the flat parameter / gradient buffers, main_cls_dgcnn.py:132-133,185) and, before the next replay, the re-pack of the binarized
+    weights it changed (_ops.PLANES.refresh: what sv_layers.py:44-48 re-derives inside every forward).  The parameters are re-homed
+    into one flat buffer first, so the step is captured anew (its graph bakes the parameter addresses in)."""
+    from svnet_amd.train import FlatAdam, FlatParams, TrainStep
+    flat = FlatParams(model)
+    step = TrainStep(model.train(), inputs, y, loss_fn)
+    step.capture()
+    opt = FlatAdam(flat, step.bucket, lr=1e-3)
+
+    def loop(n, with_opt):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step.run(all_reduce=False)
+            if with_opt:
+                opt.step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    loop(3, True)
+    t_train = loop(steps, True)
+    loss = float(step.loss)
+    t_replay = loop(steps, False)
+    return {"train_loop_ms_per_step": round(t_train, 3), "replay_only_ms_per_step": round(t_replay, 3),
+            "optimizer_and_repack_ms": round(t_train - t_replay, 3), "steps": steps, "loss_after": round(loss, 6),
+            "what": "hipGraph replay + FlatAdam.step() + re-pack of the binarized weights before the next replay, %d steps on one batch; "
+                    "replay_only = the same graph without the optimizer (nothing stale, nothing re-packed)" % steps}
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    wl = WORKLOADS[args.workload]
+    B, N, k = wl["B"], wl["N"], wl["k"]
+    if args.force_collective and world != 1:
+        print("bench.py: --force-collective is the world-size-1 leg (the N > 1 runs always reduce)", file=sys.stderr)
+        sys.exit(2)
+
+    import torch
+    import torch.distributed as dist
+    collective = world > 1 or args.force_collective
+    if collective:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if dist.get_world_size() != args.gpus:                          # the collective's own group, not the environment
+            print("bench.py: --gpus %d but the RCCL group has %d ranks" % (args.gpus, dist.get_world_size()), file=sys.stderr)
+            sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from svnet_amd import _lib, config
+    from svnet_amd.train import ForwardStep, TrainStep
+    _lib.lib()                                                        # fail loudly if the HIP library is missing
+
+    wl, model, inputs, y, loss_fn = build_workload(args.workload, dev, rank)
+    x = inputs[0]
 
     train = TrainStep(model.train(), inputs, y, loss_fn)
     if args.mode == "train":
@@ -481,7 +578,26 @@ def main():
         per_rank = [float(t.item()) for t in every]
         return max(per_rank), per_rank                                # max over the ranks is the job's time
 
-    elapsed, per_rank = timed(work.run, args.steps, args.warmup)
+    if args.force_collective and args.mode == "train":
+        def run_step():
+            work.run(all_reduce=False)
+            train.bucket.all_reduce_mean(force=True)                   # the real bucket through RCCL at world size 1
+    else:
+        run_step = work.run
+    elapsed, per_rank = timed(run_step, args.steps, args.warmup)
+    collective_us = None
+    if collective and args.mode == "train":
+        # the collective alone: HIP events around `steps` back-to-back all-reduces of the bucket, after the timed region
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            train.bucket.all_reduce_mean(force=True)
+        barrier()
+        e0.record()
+        for _ in range(args.steps):
+            train.bucket.all_reduce_mean(force=True)
+        e1.record()
+        torch.cuda.synchronize()
+        collective_us = round(e0.elapsed_time(e1) / args.steps * 1e3, 1)
     loss = float(train.loss) if (args.mode == "train" and train.loss is not None) else None
     if loss is not None and not (loss == loss and abs(loss) < 1e6):
         print("bench.py: non-finite loss %r in the timed region" % loss, file=sys.stderr)
@@ -504,6 +620,7 @@ def main():
 
     stages = per_launch = None
     launches = None
+    bucket_mb = train.bucket.flat.numel() * 4 / 1e6
     if rank == 0:
         if args.workload == "dgcnn_cls":
             per_launch, stages = dgcnn_cls_legs(args, model, x, train, work, torch, _lib)
@@ -512,6 +629,20 @@ def main():
             primary, stages = other_workload_legs(args, wl, model, inputs, train, work, torch, _lib)
         if graph_ok:
             launches = graph_kernel_nodes(work)
+
+    extras = args.workload == "dgcnn_cls" and args.mode == "train" and world == 1 and not args.no_extras and not args.no_graph
+    others = loop_leg = None
+    if rank == 0 and extras:
+        try:
+            loop_leg = train_loop_leg(model, inputs, y, loss_fn, torch, steps=20)
+        except Exception as e:
+            loop_leg = {"error": repr(e)[:300]}
+        del work, train
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        others = other_workloads_leg(args, dev, torch, _lib)
+        train = None
 
     if rank == 0:
         clouds = B * world * args.steps
@@ -528,8 +659,9 @@ def main():
                                    % (wl["name"], "fwd+loss+bwd" if args.mode == "train" else "forward only (eval)", B, N, k),
                        "global_batch": B * world, "parallelism": "dp%d" % world,
                        "collective": ("RCCL all-reduce(avg) of one %.2f MB gradient bucket per step, world size %d"
-                                      % (train.bucket.flat.numel() * 4 / 1e6, dist.get_world_size())) if world > 1 else "none (1 rank)",
-                       "rccl_world": dist.get_world_size() if world > 1 else 1,
+                                      % (bucket_mb, dist.get_world_size())) if collective else "none (1 rank)",
+                       "rccl_world": dist.get_world_size() if collective else 1,      # the collective group's own size (1 = no group)
+                       "collective_us": collective_us,
                        "launch": "hipGraph replay" if graph_ok else "eager",
                        "graph_nodes": launches,
                        # which binarized-linear kernel serves the dense layers with >= 1024 rows (both give identical integer counts)
@@ -545,11 +677,17 @@ def main():
             out["roofline_stages"] = stages
         if fwd_only:
             out["forward_only"] = fwd_only
+        if loop_leg:
+            out["train_loop"] = loop_leg
+            if "train_loop_ms_per_step" in loop_leg:
+                out["train_loop_ms_per_step"] = loop_leg["train_loop_ms_per_step"]
+        if others:
+            out["other_workloads"] = others
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, sample_b=4 if wl["model"] != "sv_dgcnn_pseg" else 2)
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -37,6 +37,10 @@ extern "C" {
  * zero-filled by the caller; the kernels leave the sums in the first L elements (the last workgroup to arrive adds the slices up). */
 #define SVNET_SLICED_LEN(L) ((SVNET_RED_SLICES + 1) * (L) + 2)
 
+/* ABI version = 100 * round-of-change + serial.  It changes whenever an entry point gains / loses an argument or a caller-owned buffer
+ * changes its required length (200: sliced accumulators, SVNET_SLICED_LEN; 400: this header).  svnet_version() returns the value the
+ * library was BUILT with: a caller compiled against another header must refuse to run (svnet_amd/_lib.py does).                   */
+#define SVNET_ABI_VERSION 400
 int svnet_version(void);
 const char* svnet_last_error(void);
 
@@ -523,6 +527,11 @@ int svnet_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n,
                         float weight_decay, int64_t step, void* stream);
 int svnet_sgd_step_f32(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float weight_decay,
                        int first_step, void* stream);
+
+/* ------------------------------------------------------------------ diagnostics (no reference counterpart)
+ * One thread writes the constant-rate device clock (s_memrealtime: 100 MHz ticks) to *slot when the stream reaches it: the start
+ * times of a captured step's launches WITHOUT a profiler (svnet_amd._lib.StepClock, tools/step_clock.py).                          */
+int svnet_stamp_u64(uint64_t* slot, void* stream);
 
 #ifdef __cplusplus
 }

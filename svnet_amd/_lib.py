@@ -10,6 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVNET_DIAG_LIB") or os.path.join(_HERE, "libsvnet_hip.so")    # (SVNET_DIAG_LIB: an ablation build, tools/ only)
 _lib = None
+ABI_VERSION = 400       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
 
 c_p = ctypes.c_void_p
 c_i64 = ctypes.c_int64
@@ -122,6 +123,7 @@ class BinHeadDesc(ctypes.Structure):
 # name -> (restype, argtypes); every symbol include/svnet_hip.h declares
 SIGNATURES = {
     "svnet_version": (c_int, []),
+    "svnet_stamp_u64": (c_int, [c_p, c_p]),
     "svnet_last_error": (ctypes.c_char_p, []),
     "svnet_knn_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
     "svnet_knn_f32": (c_int, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p, c_p, c_sz, c_p]),
@@ -222,6 +224,9 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
+        if handle.svnet_version() != ABI_VERSION:
+            raise SvnetHipError("%s was built for ABI %d, this binding speaks %d (include/svnet_hip.h SVNET_ABI_VERSION): rebuild it"
+                                % (LIB_PATH, handle.svnet_version(), ABI_VERSION))
         _lib = handle
     return _lib
 
@@ -247,9 +252,42 @@ class KernelTimer:
 TIMERS = []          # KernelTimer objects that are live (bench.py only; empty in normal operation)
 
 
+class StepClock:
+    """Diagnostic (tools/step_clock.py): start times of a step's C-ABI launches without a profiler.  While `CLOCK` is set, call()
+    puts a one-thread kernel that stores the device's 100 MHz clock in front of every launch whose entry point passes `select`, on
+    the launch's stream; captured into a HIP graph the stamps are replayed with it, and `read()` returns, for the last replay,
+    [(microseconds since the first stamp, entry point, stream id)] in time order.  Each stamp costs ~2 us of stream time."""
+
+    def __init__(self, device, select=None, slots=4096):
+        import torch
+        self.buf = torch.zeros(slots, dtype=torch.int64, device=device)
+        self.names, self.select = [], select
+
+    def mark(self, name):
+        import torch
+        if self.select is not None and not self.select(name):
+            return
+        i = len(self.names)
+        if i >= self.buf.numel():
+            return
+        st = torch.cuda.current_stream(self.buf.device)
+        self.names.append((name, st.cuda_stream))
+        lib().svnet_stamp_u64(ctypes.c_void_p(self.buf.data_ptr() + 8 * i), ctypes.c_void_p(st.cuda_stream))
+
+    def read(self):
+        t = self.buf[:len(self.names)].cpu().tolist()
+        t0 = min(t) if t else 0
+        return sorted(((x - t0) / 100.0, n, s) for x, (n, s) in zip(t, self.names))
+
+
+CLOCK = None         # a StepClock while tools/step_clock.py measures; None in normal operation
+
+
 def call(name, *args):
     """Invoke one C-ABI entry point and raise on a non-zero return code."""
     fn = getattr(lib(), name)
+    if CLOCK is not None:
+        CLOCK.mark(name)
     hit = [t for t in TIMERS if t.name == name and (t.select is None or t.select(args))] if TIMERS else None
     if hit:
         import torch

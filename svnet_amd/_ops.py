@@ -403,7 +403,8 @@ def begin_step(dev, planes_external=False, arena=None):
 
 
 def end_step():
-    global ARENA
+    global ARENA, _FUSED_COLSUMS
+    _FUSED_COLSUMS = None                                 # (the producer's [M, O] output and its arena slice are not held across steps)
     ARENA.end()
     ARENA = _DEFAULT_ARENA
     PLANES.end()
@@ -512,6 +513,7 @@ class BinLinear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W, beta, scale, bias, training=True):
+        global _FUSED_COLSUMS
         _hip(x, W, beta, scale, bias)
         ctx.training = bool(training)
         x2 = _f32c(x).reshape(-1, x.shape[-1])
@@ -533,12 +535,12 @@ class BinLinear(torch.autograd.Function):
             # many rows: int8 ternary operands on the matrix cores (same integer counts: identical outputs and planes).  In training
             # the kernel also leaves the column sums of y for the BatchNorm that follows (sv_layers.py:189): _batch_stats picks them
             # up instead of reading y again
-            global _FUSED_COLSUMS
             sums = _zeros((_sliced_len(2 * O),), torch.float64, dev) if (training and config.FUSE_BN_STATS and K <= 46340) else None
             call("svnet_binlinear_i8_fwd_f32", _p(x2), K, _p(bt), _p(packed["w_i8"]), _p(sc), _p(bias), M, K, O, _p(y),
                  _p(planes[0]), _p(planes[1]), _p(planes[2]), _p(sums), _stream())
             _FUSED_COLSUMS = (y, y._version, sums) if sums is not None else None
         else:
+            _FUSED_COLSUMS = None                         # (a stale record would keep the previous producer's output alive)
             call("svnet_binlinear_fwd_f32", _p(x2), K, _p(bt), _p(w_sign), _p(w_nz), _p(sc), _p(bias), M, K, O, _p(y),
                  _p(planes[0]), _p(planes[1]), _p(planes[2]), _stream())
         if TAP is not None:
@@ -1247,8 +1249,10 @@ class CatSink:
 
     def slot(self, B, N, Os, Ov, dev):
         """(s_ptr, s_ld, v_ptr, v_ld) of the next slice if it is (Os, Ov) wide, else None (and the sink is abandoned)."""
+        if self.filled is None:           # abandoned by an earlier level: every later one keeps its own output, result() concatenates
+            return None
         i = len(self.filled)
-        if self.filled is None or i >= len(self.ws) or (self.ws[i], self.wv[i]) != (Os, Ov):
+        if i >= len(self.ws) or (self.ws[i], self.wv[i]) != (Os, Ov):
             self.filled = None
             return None
         if self.s is None:

@@ -87,18 +87,45 @@ __device__ __forceinline__ void svnet_slice_add(T* p, T v) {
     const T old = atomicAdd(p, v);
     asm volatile("" :: "v"(old));
 }
+// How the last workgroup learns that every share is in (the ordering argument, edge by edge, with the gfx950 ISA of this function:
+// DESIGN.md 4.6, profiles/r04_slices_finish_isa.txt):
+//   (1) a thread's slice adds -> its arrival at the barrier: the adds are RETURNING agent-scope atomics, the value coming back means the
+//       read-modify-write has been performed at the memory side (float / double atomics execute there, MI355X_MICROARCH.md "Global float
+//       atomics"); the compiler waits for it (s_waitcnt vmcnt(0)) before s_barrier because the value is used;
+//   (2) every thread of the workgroup -> thread 0's counter add: the workgroup barrier (workgroup-scope release / acquire fences);
+//   (3) thread 0's counter add -> the last workgroup's loads (SVNET_SLICES_ACQREL, the default): thread 0 runs an AGENT-scope release
+//       fence (buffer_wbl2 sc1 + s_waitcnt vmcnt(0), the wait repeated in asm: ROCm 7.2 can drop the fence's own wait when the wave's
+//       scoreboard is provably empty, cdna_hip_programming.md Guideline 16 pitfall 12) in front of its relaxed counter add, and the
+//       thread that draws the last ticket an AGENT-scope acquire fence (buffer_inv sc1) behind it, before the second barrier.  So
+//       adds -> barrier -> release fence -> counter RMW -> (modification order of the counter) -> last RMW -> acquire fence -> barrier
+//       -> loads is a happens-before chain of the HSA / LLVM AMDGPU memory model (fence-fence synchronisation through the counter,
+//       cumulative over (1) and (2)), whatever the hardware does with relaxed atomics.  One release per WORKGROUP (thread 0), not
+//       per wave: the per-wave __threadfence() measured in round 3 cost 0.19 ms per step; this form is measured in DESIGN.md 4.6.
+//       With SVNET_SLICES_ACQREL=0 there are no agent-scope fences: correct only because returned atomics are performed and sc1 loads
+//       bypass the L1 on gfx950 (the "8-B agent atomics both sides" row of the guide's hand-off table) - kept as the A/B arm only.
+#ifndef SVNET_SLICES_ACQREL
+#define SVNET_SLICES_ACQREL 1
+#endif
 template <typename T>
 __device__ __forceinline__ void svnet_slices_finish(T* buf, int L) {
     __shared__ int svnet_last_wg;
-    // This thread's slice atomics (svnet_slice_add: returning, i.e. performed once their value is back) complete before the arrival is
-    // counted: the data travels ONLY in device-scope atomics executed at the memory side, so waiting for them (vmcnt)
-    // is the whole release.  (__threadfence() here - an agent-scope fence, i.e. an L2 write-back per wave on this multi-XCD part -
-    // cost 0.19 ms per step.)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned* counter = reinterpret_cast<unsigned*>(buf + (size_t)L * (1 + SVNET_RED_SLICES));
-        svnet_last_wg = atomicAdd(counter, 1u) == gridDim.x * gridDim.y * gridDim.z - 1u;
+#if SVNET_SLICES_ACQREL
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        const unsigned arrived = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = arrived == gridDim.x * gridDim.y * gridDim.z - 1u;
+#if SVNET_SLICES_ACQREL
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#endif
+        svnet_last_wg = last;
     }
     __syncthreads();
     if (svnet_last_wg) {

@@ -14,4 +14,4 @@ void svnet_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* svnet_last_error(void) { return g_err; }
-extern "C" int svnet_version(void) { return 100; /* 0.1.0 */ }
+extern "C" int svnet_version(void) { return SVNET_ABI_VERSION; }

@@ -61,3 +61,16 @@ extern "C" int svnet_sgd_step_f32(float* p, const float* g, float* buf, int64_t 
     SVNET_CHECK_LAUNCH("sgd_step_kernel");
     return SVNET_OK;
 }
+
+
+// ---- diagnostics: the device's constant-rate clock at the point the stream has reached (svnet_amd._lib.StepClock)
+namespace {
+__global__ void stamp_kernel(uint64_t* slot) { *slot = __builtin_amdgcn_s_memrealtime(); }
+}  // namespace
+
+extern "C" int svnet_stamp_u64(uint64_t* slot, void* stream) {
+    SVNET_REQUIRE(slot, SVNET_E_ARG, "svnet_stamp_u64: null slot");
+    stamp_kernel<<<1, 1, 0, (hipStream_t)stream>>>(slot);
+    SVNET_CHECK_LAUNCH("svnet_stamp_u64");
+    return SVNET_OK;
+}

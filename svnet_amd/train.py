@@ -49,13 +49,28 @@ class TrainStep:
         self._stream = None
         self._arena = _ops._ZeroArena()       # this step's zero-filled scratch: a captured graph has its addresses baked in
 
+    def _deferral_is_safe(self):
+        """config.DEFER_WGRAD hands autograd parameter gradients that the side stream has not written yet; that is sound only while
+        autograd merely ADOPTS them as .grad (never reads them on the main stream): every parameter used by ONE module only (a shared
+        one gets two gradients, added on the main stream), .grad None at backward (bucket.begin()), no tensor / post-accumulate hooks
+        (they run on the main stream).  Anything else falls back to the per-layer join."""
+        seen = set()
+        for _, p in self.model.named_parameters(remove_duplicate=False):
+            if id(p) in seen:
+                return False
+            seen.add(id(p))
+            if getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None):
+                return False
+        return True
+
     def fwd_bwd(self, planes_external=False):
         """zero_grad -> forward -> loss -> backward, gradients packed into the flat bucket (no optimizer step)."""
         _ops.begin_step(self.bucket.flat.device, planes_external, self._arena)   # one zero fill for the step's accumulators; stale packed weights rebuilt on the side stream
         try:
             self.bucket.begin()
             loss = self.loss_fn(self.model(*self.inputs), self.target)
-            _ops.DEFERRED.active = bool(config.DEFER_WGRAD)   # nothing reads a parameter gradient before pack(): see _ops._Deferred
+            # nothing reads a parameter gradient before pack() (checked: _deferral_is_safe): see _ops._Deferred
+            _ops.DEFERRED.active = bool(config.DEFER_WGRAD) and self._deferral_is_safe()
             loss.backward()
             _ops.DEFERRED.join(self.bucket.flat.device)
             self.bucket.pack()                              # one batched copy of all gradients into the flat bucket
@@ -63,10 +78,11 @@ class TrainStep:
             _ops.end_step()
         return loss.detach()
 
-    def capture(self, warmup=2):
+    def capture(self, warmup=2, before_capture=None):
         """Record fwd_bwd() into a HIP graph.  The eager warm-up steps (allocator warm-up) run on the SAME side stream that is
         then captured: autograd runs every backward node on the stream its forward ran on, so a warm-up on another stream
-        whose autograd graph is still alive (AccumulateGrad nodes) would fork the capture onto that stream."""
+        whose autograd graph is still alive (AccumulateGrad nodes) would fork the capture onto that stream.
+        `before_capture`: called between the warm-up and the capture (diagnostics: tools/step_clock.py arms its stamps there)."""
         dev = self.bucket.flat.device
         self._stream = torch.cuda.Stream(device=dev)
         self._stream.wait_stream(torch.cuda.current_stream(dev))
@@ -76,6 +92,8 @@ class TrainStep:
                 del loss
         torch.cuda.current_stream(dev).wait_stream(self._stream)
         torch.cuda.synchronize(dev)
+        if before_capture is not None:
+            before_capture()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=self._stream):
             self.loss = self.fwd_bwd(planes_external=True)    # (the packing launches stay outside the graph: run() refreshes what is stale)

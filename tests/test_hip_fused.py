@@ -294,3 +294,53 @@ def test_bn_pool_fused_equals_bn_act_then_pool(training, hip_device):
     for n in ("dy", "db", "dgamma", "dbeta"):
         a_, b_ = res[True][n], res[False][n]
         assert float((a_ - b_).abs().max()) <= 1e-5 * max(float(b_.abs().max()), 1e-6), n
+
+
+# ----------------------------------------------------------------------------- CatSink with a level that is not fused
+
+_SINK_LEVELS = [((32, 10), (32, 10)), ((32, 10), (32, 10)), ((32, 10), (64, 21)), ((64, 21), (128, 42))]
+
+
+@pytest.mark.parametrize("layerwise_level", [None, 0, 1], ids=["all_fused", "first_layerwise", "second_layerwise"])
+def test_cat_sink_with_a_layerwise_level_falls_back_to_cat(layerwise_level, hip_device):
+    """A pyramid of four edge levels (widths 32/10, 32/10, 64/21, 128/42) under one CatSink, ONE of them forced onto the layer-wise
+    path (a non-default BatchNorm momentum: SVBlock._default_bn).  Second level layer-wise: the third asks for slot 1 with other widths,
+    the sink is abandoned, and the fourth used to crash in CatSink.slot() (len() of None).  First level layer-wise: the second level's
+    kernel lands in slot 0 (same widths) before the third abandons the sink; result() must return torch.cat.  Every way the
+    concatenation and every gradient equal those of the same pyramid run WITHOUT a sink (identical kernels, torch.cat + autograd's adds)."""
+    from svnet_amd import _ops
+    from svnet_amd.models.utils.sv_util import get_graph_feature_sv, svpool
+    k, B, N = 6, 2, 96
+    outs = {}
+    for use_sink in (True, False):
+        blocks = []
+        for i, (cin, cout) in enumerate(_SINK_LEVELS):
+            blk, _, s, v, _ = _make((cin, cout, B, N, k), hip_device, True, "sink_lvl%d" % i)
+            if i == layerwise_level:
+                blk.bn1.momentum = 0.2                      # running statistics only: outputs and gradients are unaffected
+            if i == 0:
+                leaves = (s.to(hip_device).requires_grad_(True), v.to(hip_device).requires_grad_(True))
+            blocks.append(blk)
+        level, pyramid = leaves, []
+        sink = _ops.CatSink([c[1][0] for c in _SINK_LEVELS], [c[1][1] for c in _SINK_LEVELS])
+        with (sink if use_sink else contextlib.nullcontext()):
+            for blk in blocks:
+                level = svpool(blk(get_graph_feature_sv(level, k=k)))
+                pyramid.append(level)
+        if use_sink:
+            s_cat, v_cat = sink.result(pyramid)
+            in_place = sink.filled is not None and len(sink.filled) == len(blocks)
+            assert in_place == (layerwise_level is None)
+        else:
+            s_cat, v_cat = torch.cat([x[0] for x in pyramid], -1), torch.cat([x[1] for x in pyramid], -1)
+        rs = C.t("sink/rs", tuple(s_cat.shape)).to(hip_device)
+        rv = C.t("sink/rv", tuple(v_cat.shape)).to(hip_device)
+        ((s_cat * rs).sum() + (v_cat * rv).sum()).backward()
+        g = {"out0": s_cat.detach().cpu().numpy(), "out1": v_cat.detach().cpu().numpy(),
+             "dx0": leaves[0].grad.cpu().numpy(), "dx1": leaves[1].grad.cpu().numpy()}
+        for i, blk in enumerate(blocks):
+            for n, p in blk.named_parameters():
+                g["d:%d.%s" % (i, n)] = p.grad.cpu().numpy()
+        outs[use_sink] = g
+    assert np.array_equal(outs[True]["out0"], outs[False]["out0"]) and np.array_equal(outs[True]["out1"], outs[False]["out1"])
+    compare_case(outs[True], outs[False], 1e-4, "pyramid with a layer-wise level: sink vs no sink")

@@ -35,7 +35,7 @@ def _api(dev):
 
 def test_library_is_loaded_and_native(hip_device):
     from svnet_amd import _lib
-    assert _lib.lib().svnet_version() >= 100
+    assert _lib.lib().svnet_version() == _lib.ABI_VERSION
     assert os.path.exists(_lib.LIB_PATH)
 
 

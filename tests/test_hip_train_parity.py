@@ -90,10 +90,15 @@ TRAIN_CASES = [c for c in C.MODEL_CASES if c[0].endswith("_small") and c[0] != "
     ("pseg_bin_b32", "sv_dgcnn_pseg", True, 32, 32, 6), ("pseg_fp_b32", "sv_dgcnn_pseg", False, 32, 32, 6),
     ("pointnet_bin_b16", "sv_pointnet_cls", True, 16, 64, 8), ("pointnet_fp_b32", "sv_pointnet_cls", False, 32, 32, 6),
     ("ppseg_fp_b16", "sv_pointnet_pseg", False, 16, 64, 8),
+    # the bench's own shape (N = 1024, k = 20; B = 8 so that the XCD-aware cloud order is in play): the N = 1024 kernel instantiations -
+    # knn_main<16,4,...>, the conv4 tile kernel <0,8,44>, mfma_tn_aff2, chunked reverse lists, sliced sums over thousands of workgroups -
+    # chained against the oracle, where the other cases stop at N = 128 (sv_dgcnn_cls.py:46-82)
+    ("dgcnn_bin_n1024", "sv_dgcnn_cls", True, 8, 1024, 20),
 ]
 # cases held to the north-star tolerance itself (1e-3) on every tensor, whatever the yard-sticks say
 STRICT = ("dgcnn_bin_small", "dgcnn_fp_small", "pseg_bin_small", "dgcnn_bin_b16", "dgcnn_bin_b16b", "dgcnn_bin_b8", "dgcnn_fp_b16",
-          "pseg_bin_b32", "pseg_fp_b32")
+          "pseg_bin_b32", "pseg_fp_b32", "dgcnn_bin_n1024")
+NO_SENSITIVITY_LEG = ("dgcnn_bin_n1024",)      # STRICT cases never use the float64 sensitivity (a third oracle step: ~1 min at this size)
 YARDSTICK = 3.0         # a tensor may be this many times further from the float64 truth than the fp32 oracle is ...
 SENSITIVITY = 10.0      # ... or this many times what the float64 truth itself moves when its input moves by one part in 1e7
 
@@ -149,13 +154,16 @@ def _train_step_case(case, hip_device, corrupt=None):
     # d:fc1.weight of pointnet_fp_small moved 1.6e-3 under the first direction while the HIP step's error there went from 4e-3 to 1.6e-2
     # when ONE forward GEMM changed its summation order), so the ill-conditioned cases take the largest move over three directions
     e_sens, l_sens_all = {}, []
-    for probe in range(1 if tag in STRICT else 3):
+    for probe in range(0 if tag in NO_SENSITIVITY_LEG else 1 if tag in STRICT else 3):
         wiggle = torch.from_numpy(np.sign(synth.normal(99 + probe, 1, tuple(x.shape)))).double()
         lo64w, _, Pg64w = oracle_step(model, binary, k, x.double() * (1.0 + 1e-7 * wiggle), l, y, decisions_of(tap, model=dmodel), torch.float64)
         for n, e in case_errors({"d:" + n: Pg64w[n].grad.numpy() for n in names}, truth).items():
             e_sens[n] = max(e, e_sens.get(n, 0.0))
         l_sens_all.append(lo64w)
-    l_sens = max(H.max_rel_err(w.numpy(), lo64.numpy()) for w in l_sens_all)
+    l_sens = max([H.max_rel_err(w.numpy(), lo64.numpy()) for w in l_sens_all], default=0.0)
+    if not e_sens:
+        assert tag in STRICT
+        e_sens = {"d:" + n: 0.0 for n in names}
     ref = {"d:" + n: Pg[n].grad.numpy() for n in names}
     e_hip, e_orc = case_errors(got, truth), case_errors(ref, truth)
     l_hip, l_orc = H.max_rel_err(logits, lo64.numpy()), H.max_rel_err(lo.numpy(), lo64.numpy())
