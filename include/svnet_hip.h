@@ -33,14 +33,21 @@ extern "C" {
  * address are served one after the other at the memory side and set the pace of the reduction kernels.                            */
 #define SVNET_RED_SLICES 16
 /* Length (elements) of a SLICED accumulator of L sums (svnet_colstats_f64, svnet_bn_act_bwd_reduce_f32, svnet_vbn_bwd_reduce_f32,
- * svnet_bn_pool_bwd_f32, the col_sums of svnet_binlinear_i8_fwd_f32): [L result | SVNET_RED_SLICES x L slices | arrival counter],
- * zero-filled by the caller; the kernels leave the sums in the first L elements (the last workgroup to arrive adds the slices up). */
+ * svnet_bn_pool_bwd_f32, the col_sums of svnet_binlinear_i8_fwd_f32): [L totals | SVNET_RED_SLICES x L slices | 2 spare], zero-filled by
+ * the caller.  The REDUCING entry point only fills the slices; the totals (first L elements) are written by the entry point that
+ * CONSUMES the accumulator (svnet_bn_finalize_f32, svnet_bn_act_bwd_apply_f32, svnet_vbn_bwd_apply_f32, the apply pass of
+ * svnet_bn_pool_bwd_f32; svnet_vbn_fwd_stats_f32 reads the slices and writes no totals) or by svnet_slices_sum_f32 / _f64 - i.e. the
+ * slices are handed from their adders to their reader across a kernel boundary of the stream, never inside a launch.               */
 #define SVNET_SLICED_LEN(L) ((SVNET_RED_SLICES + 1) * (L) + 2)
+/* buf[0:L] = sum over the slices of a sliced accumulator (for a caller that reads the totals itself). */
+int svnet_slices_sum_f32(float* buf, int64_t L, void* stream);
+int svnet_slices_sum_f64(double* buf, int64_t L, void* stream);
 
 /* ABI version = 100 * round-of-change + serial.  It changes whenever an entry point gains / loses an argument or a caller-owned buffer
- * changes its required length (200: sliced accumulators, SVNET_SLICED_LEN; 400: this header).  svnet_version() returns the value the
+ * changes its required length (200: sliced accumulators, SVNET_SLICED_LEN; 400: this header; 401: the totals of a sliced accumulator are
+ * written by its consumer, svnet_slices_sum_*).  svnet_version() returns the value the
  * library was BUILT with: a caller compiled against another header must refuse to run (svnet_amd/_lib.py does).                   */
-#define SVNET_ABI_VERSION 400
+#define SVNET_ABI_VERSION 401
 int svnet_version(void);
 const char* svnet_last_error(void);
 
@@ -363,8 +370,9 @@ int svnet_vproject_bwd_f32(const float* v, const float* z, const float* ds, int6
  * zero-filled by the caller).
  * kind 0: x is [M,C];  kind 1: x is [M,3,C] and the statistic is n = ||x[m,:,c]||_2 + 1e-6 (VectorBN, :94). */
 int svnet_colstats_f64(const float* x, int64_t M, int64_t C, int kind, double* sums, void* stream);
-/* mean/invstd from the sums (training), running-stat update and num_batches_tracked += 1 (each may be NULL). */
-int svnet_bn_finalize_f32(const double* sums, int64_t M, int64_t C, float eps, float momentum, float* mean,
+/* mean/invstd from the sums (training: `sums` = the sliced accumulator svnet_colstats_f64 / svnet_binlinear_i8_fwd_f32 filled; its totals
+ * are left in sums[0:2C]), running-stat update and num_batches_tracked += 1 (each may be NULL). */
+int svnet_bn_finalize_f32(double* sums, int64_t M, int64_t C, float eps, float momentum, float* mean,
                           float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                           void* stream);
 /* eval mode: mean = running_mean, invstd = 1/sqrt(running_var+eps).                                 */
@@ -374,13 +382,13 @@ int svnet_bn_eval_stats_f32(const float* running_mean, const float* running_var,
 int svnet_bn_act_fwd_f32(const float* x, const float* mean, const float* invstd, const float* gamma,
                          const float* beta, int64_t M, int64_t C, int act, float slope, float* y, void* stream);
 /* backward, pass 1: red[0:C] = sum g', red[C:2C] = sum g'*xhat (`red`: a sliced accumulator of 2*C floats, SVNET_SLICED_LEN(2*C), zero-filled),
- * g' = g * act'(bn(x)).  pass 2: dx; train_stats=1 subtracts the batch-statistic terms.
- * dgamma = red[C:2C], dbeta = red[0:C] (the caller adds them to the parameter grads).              */
+ * g' = g * act'(bn(x)).  pass 2: dx; train_stats=1 subtracts the batch-statistic terms; it adds the slices of `red` up and leaves
+ * dgamma = red[C:2C], dbeta = red[0:C] (without pass 2: svnet_slices_sum_f32(red, 2C)).           */
 int svnet_bn_act_bwd_reduce_f32(const float* g, const float* x, const float* mean, const float* invstd,
                                 const float* gamma, const float* beta, int64_t M, int64_t C, int act, float slope,
                                 float* red, void* stream);
 int svnet_bn_act_bwd_apply_f32(const float* g, const float* x, const float* mean, const float* invstd,
-                               const float* gamma, const float* beta, const float* red, int64_t M, int64_t C, int act,
+                               const float* gamma, const float* beta, float* red, int64_t M, int64_t C, int act,
                                float slope, int train_stats, float* dx, void* stream);
 
 /* ------------------------------------------------------------------ VectorBN (+ gate)  (sv_layers.py:81-102, :194)
@@ -400,7 +408,7 @@ int svnet_vbn_bwd_reduce_f32(const float* g, const float* v, const float* mean, 
                              const float* gamma, const float* beta, const float* gate, int64_t rows_per_batch,
                              int64_t M, int64_t C, float* red, float* dgate, void* stream);
 int svnet_vbn_bwd_apply_f32(const float* g, const float* v, const float* mean, const float* invstd,
-                            const float* gamma, const float* beta, const float* gate, const float* red,
+                            const float* gamma, const float* beta, const float* gate, float* red,
                             int64_t rows_per_batch, int64_t M, int64_t C, int train_stats, float* dv, void* stream);
 
 /* ------------------------------------------------------------------ pooling (sv_util.py:118-132 svpool; adaptive pools of sv_dgcnn_cls.py:72-73)

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVNET_DIAG_LIB") or os.path.join(_HERE, "libsvnet_hip.so")    # (SVNET_DIAG_LIB: an ablation build, tools/ only)
 _lib = None
-ABI_VERSION = 400       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
+ABI_VERSION = 401       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
 
 c_p = ctypes.c_void_p
 c_i64 = ctypes.c_int64
@@ -124,6 +124,8 @@ class BinHeadDesc(ctypes.Structure):
 SIGNATURES = {
     "svnet_version": (c_int, []),
     "svnet_stamp_u64": (c_int, [c_p, c_p]),
+    "svnet_slices_sum_f32": (c_int, [c_p, c_i64, c_p]),
+    "svnet_slices_sum_f64": (c_int, [c_p, c_i64, c_p]),
     "svnet_last_error": (ctypes.c_char_p, []),
     "svnet_knn_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
     "svnet_knn_f32": (c_int, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p, c_p, c_sz, c_p]),

@@ -64,7 +64,9 @@ def gemm(M, N, K, B, b_rs, b_cs, C, ldc, A=None, a_rs=0, a_cs=0, a_scale=None, a
     d.split_k, d.accumulate = split_k, int(accumulate)
     d.tern_tile_mask = tern_tile_mask
     ws = None
-    if b_exact and A is not None and M >= 8192 and K >= 128 and N >= 64:   # big product against sign weights: let the library pack B once
+    # big product against sign weights: let the library pack B once (K >= 64 with more than 128 columns: the LDS-tiled rows kernel,
+    # mfma_rows2_kernel, whose A tile arrives in coalesced row pieces whatever the row alignment - conv5's linear2, K = 83)
+    if b_exact and A is not None and M >= 8192 and N >= 64 and (K >= 128 or (K >= config.ROWS2_MIN_K and N > 128)):
         nbytes = _lib.lib().svnet_gemm_workspace_bytes(N, K)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=C.device)
         d.workspace, d.workspace_bytes = _p(ws), nbytes
@@ -712,10 +714,11 @@ class V2SCat(torch.autograd.Function):
     the gradient on as a view and reads the Vector2Scalar part where it lies (svnet_v2s_bwd_ld_f32)."""
 
     @staticmethod
-    def forward(ctx, s, v, W, scale, training=True, clouds=0):
+    def forward(ctx, s, v, W, scale, training=True, clouds=0, mean_on_side=False):
         """clouds > 0: also returns mean(s) over each cloud's rows [clouds, Cs] (the gate's input, sv_layers.py:179): s then has ONE
         consumer in the autograd graph, and the backward writes its gradient once - the cat gradient's s columns plus the mean's
-        broadcast - instead of a broadcast pass and a strided add of two gradients in front of the layer's backward."""
+        broadcast - instead of a broadcast pass and a strided add of two gradients in front of the layer's backward.
+        mean_on_side: the mean is computed on the side stream (its consumer - the gate MLP, then VectorBN - lives there)."""
         _hip(s, v, W, scale)
         ctx.training = bool(training)
         v3 = _f32c(v).reshape(-1, 3, v.shape[-1])
@@ -730,6 +733,12 @@ class V2SCat(torch.autograd.Function):
         else:
             sc, w_eff = None, W
         out = torch.empty((M, Cs + C * J), dtype=torch.float32, device=v.device)
+        s_mean = None
+        if clouds and mean_on_side:
+            main, side = torch.cuda.current_stream(v.device), _side_stream(v.device)
+            side.wait_stream(main)                       # (s2 may be a copy this stream has just made)
+            with torch.cuda.stream(side):
+                s_mean, _ = pool_raw(s2, clouds, M // clouds, Cs, 1)
         call("svnet_v2s_cat_fwd_f32", _p(v3), _p(w_eff), _p(s2), Cs, M, C, J, _p(out), Cs + C * J, _stream())
         ctx.save_for_backward(v3, W, w_eff, sc)
         ctx.meta = (M, C, J, Cs, s.shape, v.shape, None if scale is None else scale.shape)
@@ -737,7 +746,8 @@ class V2SCat(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         cat = out.view(s.shape[:-1] + (Cs + C * J,))
         if clouds:
-            s_mean, _ = pool_raw(s2, clouds, M // clouds, Cs, 1)
+            if s_mean is None:
+                s_mean, _ = pool_raw(s2, clouds, M // clouds, Cs, 1)
             return cat, s_mean
         return cat
 
@@ -764,7 +774,7 @@ class V2SCat(torch.autograd.Function):
         if sc is not None:
             dW, dsc = _binweight_grad(GX, W, sc, J, C, ctx.training)
             dsc = dsc.view(scshape)
-        return ds, dv.view(vshape), dW, dsc, None, None
+        return ds, dv.view(vshape), dW, dsc, None, None, None
 
 
 class VProject(torch.autograd.Function):
@@ -862,6 +872,8 @@ class BNAct(torch.autograd.Function):
             call("svnet_bn_act_bwd_apply_f32", _p(g2), _p(x2), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(red), M, C, act, slope,
                                                int(training), _p(dx), _stream())
             dx = dx.view(xshape)
+        else:
+            call("svnet_slices_sum_f32", _p(red), 2 * C, _stream())      # (the apply pass leaves the totals in red[0:2C]; without it: here)
         return dx, red[C:2 * C], red[:C], None, None, None, None, None, None, None, None
 
 
@@ -909,6 +921,8 @@ class VBN(torch.autograd.Function):
             call("svnet_vbn_bwd_apply_f32", _p(g3), _p(v3), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(gate2), _p(red), rpb, M, C,
                                             int(training), _p(dv), _stream())
             dv = dv.view(vshape)
+        else:
+            call("svnet_slices_sum_f32", _p(red), 2 * C, _stream())
         if dgate is not None:
             dgate = dgate.view(gshape)
         return dv, red[C:2 * C], red[:C], None, None, dgate, None, None, None, None, None

@@ -41,3 +41,8 @@ FUSE_HEAD = True
 # (svnet_amd._ops._Deferred); False = every backward joins before it returns
 DEFER_WGRAD = True
 VEC_EARLY = True
+# SVBlock on rows (two streams): the gate's chain - per-cloud mean of s, MLP - on the side stream behind linear2's product, beside linear1
+# on the main stream (its only consumer, VectorBN, lives on the side stream)
+GATE_ON_SIDE = True
+# sign-weight products with many rows and more than 128 columns go to the LDS-tiled rows kernel from this K on (it needs K >= 64)
+ROWS2_MIN_K = 64

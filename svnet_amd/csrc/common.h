@@ -69,75 +69,29 @@ __device__ __forceinline__ float wave_sum(float v) { return group_sum_dpp<64>(v)
 // workgroup onto the SAME L addresses; same-address atomics are served one after the other at the memory side (~2.5 ns each per cache
 // line, measured: 512 workgroups x 340 doubles = 12 us of a 39 us kernel, the float reductions twice that), and removing them from
 // the BatchNorm / VectorBN reductions of one step was worth 0.065 ms.  Now the caller's (zero-filled) buffer holds
-//   [L result | SVNET_RED_SLICES x L slices | arrival counter]       (SVNET_SLICED_LEN(L) elements, svnet_hip.h)
-// workgroup w adds to slice w % SVNET_RED_SLICES, and the LAST workgroup to arrive adds the slices up in a fixed order into the
-// first L elements - what every consumer reads, unchanged.
+//   [L result | SVNET_RED_SLICES x L slices | 2 spare]               (SVNET_SLICED_LEN(L) elements, svnet_hip.h)
+// workgroup w adds to slice w % SVNET_RED_SLICES and NOTHING else happens in the reducing kernel: the slices are added up by the
+// kernel that consumes the sums (svnet_slices_total: bn_finalize / vbn_fwd / the *_bwd_apply kernels, each of which also leaves the
+// totals in the first L elements), or by svnet_slices_sum_* where no such kernel follows.  The hand-off between the adders and the
+// reader is therefore a KERNEL BOUNDARY on one stream - the only inter-workgroup ordering HIP guarantees without a protocol.
+// (Round 3 summed the slices in the reducing kernel's last workgroup to arrive, ordered by returning atomics + an arrival counter;
+//  one run of its no-return form lost a share.  The memory-model-conforming form of that hand-off - an agent-scope release fence by
+//  one thread per workgroup in front of the counter add, an acquire fence in the last arriver - measured +0.05 ms per step
+//  (4.657 against 4.606 ms, three alternating runs on one box, gpurun_out/r04_ab_slices.log); this form needs no hand-off at all.)
 template <typename T>
 __device__ __forceinline__ T* svnet_slice_ptr(T* buf, int L) {
     const unsigned w = blockIdx.x + blockIdx.y * gridDim.x;
     return buf + (size_t)L * (1u + (w & (SVNET_RED_SLICES - 1)));
 }
-// The add into a slice, RETURNING: the old value coming back means the read-modify-write HAS been performed at the point of
-// coherence, so "wait for my memory operations" before the arrival is counted really orders the sums before the counter.  (A
-// no-return atomic is acknowledged when the L2 has accepted it, not when the memory side has executed it: with those, one run in a
-// few hundred summed a slice that was still missing a workgroup's share - a 6 % error in a BatchNorm gradient at step 4 of a five-step
-// test, nothing in the other 245 tests.)
 template <typename T>
-__device__ __forceinline__ void svnet_slice_add(T* p, T v) {
-    const T old = atomicAdd(p, v);
-    asm volatile("" :: "v"(old));
-}
-// How the last workgroup learns that every share is in (the ordering argument, edge by edge, with the gfx950 ISA of this function:
-// DESIGN.md 4.6, profiles/r04_slices_finish_isa.txt):
-//   (1) a thread's slice adds -> its arrival at the barrier: the adds are RETURNING agent-scope atomics, the value coming back means the
-//       read-modify-write has been performed at the memory side (float / double atomics execute there, MI355X_MICROARCH.md "Global float
-//       atomics"); the compiler waits for it (s_waitcnt vmcnt(0)) before s_barrier because the value is used;
-//   (2) every thread of the workgroup -> thread 0's counter add: the workgroup barrier (workgroup-scope release / acquire fences);
-//   (3) thread 0's counter add -> the last workgroup's loads (SVNET_SLICES_ACQREL, the default): thread 0 runs an AGENT-scope release
-//       fence (buffer_wbl2 sc1 + s_waitcnt vmcnt(0), the wait repeated in asm: ROCm 7.2 can drop the fence's own wait when the wave's
-//       scoreboard is provably empty, cdna_hip_programming.md Guideline 16 pitfall 12) in front of its relaxed counter add, and the
-//       thread that draws the last ticket an AGENT-scope acquire fence (buffer_inv sc1) behind it, before the second barrier.  So
-//       adds -> barrier -> release fence -> counter RMW -> (modification order of the counter) -> last RMW -> acquire fence -> barrier
-//       -> loads is a happens-before chain of the HSA / LLVM AMDGPU memory model (fence-fence synchronisation through the counter,
-//       cumulative over (1) and (2)), whatever the hardware does with relaxed atomics.  One release per WORKGROUP (thread 0), not
-//       per wave: the per-wave __threadfence() measured in round 3 cost 0.19 ms per step; this form is measured in DESIGN.md 4.6.
-//       With SVNET_SLICES_ACQREL=0 there are no agent-scope fences: correct only because returned atomics are performed and sc1 loads
-//       bypass the L1 on gfx950 (the "8-B agent atomics both sides" row of the guide's hand-off table) - kept as the A/B arm only.
-#ifndef SVNET_SLICES_ACQREL
-#define SVNET_SLICES_ACQREL 1
-#endif
+__device__ __forceinline__ void svnet_slice_add(T* p, T v) { atomicAdd(p, v); }
+// Sum i of a sliced accumulator a PREVIOUS kernel of the stream filled (fixed order: bit-reproducible for a given set of slice values).
 template <typename T>
-__device__ __forceinline__ void svnet_slices_finish(T* buf, int L) {
-    __shared__ int svnet_last_wg;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned* counter = reinterpret_cast<unsigned*>(buf + (size_t)L * (1 + SVNET_RED_SLICES));
-#if SVNET_SLICES_ACQREL
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        const unsigned arrived = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = arrived == gridDim.x * gridDim.y * gridDim.z - 1u;
-#if SVNET_SLICES_ACQREL
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-#endif
-        svnet_last_wg = last;
-    }
-    __syncthreads();
-    if (svnet_last_wg) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        for (int i = threadIdx.x; i < L; i += blockDim.x) {
-            T s = 0;
+__device__ __forceinline__ T svnet_slices_total(const T* buf, int L, int i) {
+    T s = 0;
 #pragma unroll
-            for (int sl = 0; sl < SVNET_RED_SLICES; ++sl)
-                s += __hip_atomic_load(&buf[(size_t)L * (1 + sl) + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            buf[i] = s;
-        }
-    }
+    for (int sl = 0; sl < SVNET_RED_SLICES; ++sl) s += buf[(size_t)L * (1 + sl) + i];
+    return s;
 }
 
 __device__ __forceinline__ double wave_sum(double v) {

@@ -109,17 +109,20 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
         double* sl = svnet_slice_ptr(sums, 2 * (int)C);
         block_col_reduce<2>(acc, col_in, rl, RL, CW, ok, lds, sl, sl + C, c, nullptr, nullptr);
     }
-    svnet_slices_finish(sums, 2 * (int)C);
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, int64_t M, int64_t C, float eps, float momentum,
+__global__ void bn_finalize_kernel(double* __restrict__ sums, int64_t M, int64_t C, float eps, float momentum,
                                    float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ rmean,
                                    float* __restrict__ rvar, long long* __restrict__ nbt) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && nbt) *nbt += 1;
     if (c >= C) return;
-    const double m = sums[c] / (double)M;
-    double var = sums[C + c] / (double)M - m * m;
+    // `sums`: a sliced accumulator a previous kernel filled (colstats_kernel, binlinear_i8_fwd_kernel); the totals are left in its first 2C
+    const double t0 = svnet_slices_total(sums, 2 * (int)C, (int)c), t1 = svnet_slices_total(sums, 2 * (int)C, (int)(C + c));
+    sums[c] = t0;
+    sums[C + c] = t1;
+    const double m = t0 / (double)M;
+    double var = t1 / (double)M - m * m;
     if (var < 0.0) var = 0.0;
     mean[c] = (float)m;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -203,18 +206,20 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
         float* sl = svnet_slice_ptr(red, 2 * (int)C);
         block_col_reduce<2>(acc, col_in, rl, RL, CW, ok, lds, nullptr, nullptr, c, sl, sl + C);
     }
-    svnet_slices_finish(red, 2 * (int)C);
 }
 
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               const float* __restrict__ red, int64_t M, int64_t C, int act,
+                                                               float* __restrict__ red, int64_t M, int64_t C, int act,
                                                                float slope, int train_stats, int cw_shift, float* __restrict__ dx) {
     SVNET_ELEM_PROLOGUE();
     const float invM = 1.f / (float)M;
     for (int64_t c = col_in; c < C; c += CW) {
-        const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c], r0c = red[c], r1c = red[C + c];
+        // (`red`: the slices the reduce kernel filled; workgroup 0 leaves the totals - dL/dbeta, dL/dgamma - in its first 2C elements)
+        const float r0c = svnet_slices_total(red, 2 * (int)C, (int)c), r1c = svnet_slices_total(red, 2 * (int)C, (int)(C + c));
+        if (blockIdx.x == 0 && rl == 0) { red[c] = r0c; red[C + c] = r1c; }
+        const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
 #pragma unroll 4
         for (int64_t r = rstart; r < M; r += rstride) {
             const float xh = (x[r * C + c] - mu) * is;
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
 // Statistics of the fused form (svnet_vbn_fwd_stats_f32): every thread derives mean / invstd of its channel from the fp64 sums itself
 // (bn_finalize_kernel's arithmetic) and workgroup 0 keeps them + updates the running statistics - the one-workgroup finalize launch
 // between the statistics pass and this kernel is gone (beside a kernel that fills the chip it waited up to 60 us for a free CU).
-struct VbnStats {
+struct VbnStats {      // sums: the sliced accumulator colstats_kernel filled - every thread adds the slices of its channel up itself
     const double* sums; float* mean_out; float* invstd_out; float* rmean; float* rvar; long long* nbt;
     float eps, momentum;
 };
@@ -252,8 +257,8 @@ __global__ __launch_bounds__(256) void vbn_fwd_kernel(const float* __restrict__ 
     for (int64_t c = col_in; c < C; c += CW) {
         float mu, is;
         if (FUSED) {
-            const double m = st.sums[c] / (double)M;
-            double var = st.sums[C + c] / (double)M - m * m;
+            const double m = svnet_slices_total(st.sums, 2 * (int)C, (int)c) / (double)M;
+            double var = svnet_slices_total(st.sums, 2 * (int)C, (int)(C + c)) / (double)M - m * m;
             if (var < 0.0) var = 0.0;
             mu = (float)m;
             is = (float)(1.0 / sqrt(var + (double)st.eps));
@@ -347,19 +352,20 @@ __global__ __launch_bounds__(256) void vbn_bwd_reduce_kernel(const float* __rest
         float* sl = svnet_slice_ptr(red, 2 * (int)C);
         block_col_reduce<2>(acc, col_in, rl, RL, CW, ok, lds, nullptr, nullptr, c, sl, sl + C);
     }
-    svnet_slices_finish(red, 2 * (int)C);
 }
 
 __global__ __launch_bounds__(256) void vbn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ v,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            const float* __restrict__ gate, const float* __restrict__ red,
+                                                            const float* __restrict__ gate, float* __restrict__ red,
                                                             int64_t rpb, int64_t M, int64_t C, int train_stats, int cw_shift,
                                                             float* __restrict__ dv) {
     SVNET_ELEM_PROLOGUE();
     const float invM = 1.f / (float)M;
     for (int64_t c = col_in; c < C; c += CW) {
-        const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c], r0c = red[c], r1c = red[C + c];
+        const float r0c = svnet_slices_total(red, 2 * (int)C, (int)c), r1c = svnet_slices_total(red, 2 * (int)C, (int)(C + c));
+        if (blockIdx.x == 0 && rl == 0) { red[c] = r0c; red[C + c] = r1c; }
+        const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
         SVNET_CLOUD_CURSOR();
 #pragma unroll 2
         for (int64_t m = rstart; m < M; m += rstride) {
@@ -419,7 +425,7 @@ extern "C" int svnet_colstats_f64(const float* x, int64_t M, int64_t C, int kind
     return SVNET_OK;
 }
 
-extern "C" int svnet_bn_finalize_f32(const double* sums, int64_t M, int64_t C, float eps, float momentum, float* mean,
+extern "C" int svnet_bn_finalize_f32(double* sums, int64_t M, int64_t C, float eps, float momentum, float* mean,
                                      float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                      void* stream) {
     SVNET_REQUIRE(sums && mean && invstd && M > 0 && C > 0, SVNET_E_ARG, "svnet_bn_finalize_f32: bad arguments");
@@ -463,7 +469,7 @@ extern "C" int svnet_bn_act_bwd_reduce_f32(const float* g, const float* x, const
 }
 
 extern "C" int svnet_bn_act_bwd_apply_f32(const float* g, const float* x, const float* mean, const float* invstd,
-                                          const float* gamma, const float* beta, const float* red, int64_t M, int64_t C, int act,
+                                          const float* gamma, const float* beta, float* red, int64_t M, int64_t C, int act,
                                           float slope, int train_stats, float* dx, void* stream) {
     SVNET_REQUIRE(g && x && mean && invstd && gamma && beta && red && dx && M >= 0 && C > 0, SVNET_E_ARG, "svnet_bn_act_bwd_apply_f32: bad arguments");
     if (M == 0) return SVNET_OK;
@@ -516,7 +522,7 @@ extern "C" int svnet_vbn_bwd_reduce_f32(const float* g, const float* v, const fl
 }
 
 extern "C" int svnet_vbn_bwd_apply_f32(const float* g, const float* v, const float* mean, const float* invstd,
-                                       const float* gamma, const float* beta, const float* gate, const float* red,
+                                       const float* gamma, const float* beta, const float* gate, float* red,
                                        int64_t rows_per_batch, int64_t M, int64_t C, int train_stats, float* dv, void* stream) {
     SVNET_REQUIRE(g && v && mean && invstd && gamma && beta && red && dv && M >= 0 && C > 0 && rows_per_batch > 0, SVNET_E_ARG, "svnet_vbn_bwd_apply_f32: bad arguments");
     if (M == 0) return SVNET_OK;
@@ -525,5 +531,29 @@ extern "C" int svnet_vbn_bwd_apply_f32(const float* g, const float* v, const flo
     hipLaunchKernelGGL(vbn_bwd_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, v, mean, invstd, gamma, beta, gate, red,
                        rows_per_batch, M, C, train_stats, cw, dv);
     SVNET_CHECK_LAUNCH("vbn_bwd_apply_kernel");
+    return SVNET_OK;
+}
+
+
+// ---- the totals of a sliced accumulator where no consuming kernel of ours follows (svnet_hip.h SVNET_SLICED_LEN): buf[0:L] = sum of the slices
+namespace {
+template <typename T>
+__global__ void slices_sum_kernel(T* __restrict__ buf, int L) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < L) buf[i] = svnet_slices_total(buf, L, i);
+}
+}  // namespace
+
+extern "C" int svnet_slices_sum_f32(float* buf, int64_t L, void* stream) {
+    SVNET_REQUIRE(buf && L > 0 && L < ((int64_t)1 << 30), SVNET_E_ARG, "svnet_slices_sum_f32: bad arguments");
+    hipLaunchKernelGGL(slices_sum_kernel<float>, dim3((unsigned)svnet_cdiv(L, 256)), dim3(256), 0, (hipStream_t)stream, buf, (int)L);
+    SVNET_CHECK_LAUNCH("slices_sum_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_slices_sum_f64(double* buf, int64_t L, void* stream) {
+    SVNET_REQUIRE(buf && L > 0 && L < ((int64_t)1 << 30), SVNET_E_ARG, "svnet_slices_sum_f64: bad arguments");
+    hipLaunchKernelGGL(slices_sum_kernel<double>, dim3((unsigned)svnet_cdiv(L, 256)), dim3(256), 0, (hipStream_t)stream, buf, (int)L);
+    SVNET_CHECK_LAUNCH("slices_sum_kernel");
     return SVNET_OK;
 }

@@ -220,20 +220,22 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float* __
         svnet_slice_add(&sl[i], (float)a0);
         svnet_slice_add(&sl[inner + i], (float)a1);
     }
-    svnet_slices_finish(red, 2 * (int)inner);
 }
 __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* __restrict__ gmax, const float* __restrict__ gmean, int64_t g_ld,
                                                                 const int32_t* __restrict__ argmax, const float* __restrict__ x,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                const float* __restrict__ red, int act, float slope, int train_stats,
+                                                                float* __restrict__ red, int act, float slope, int train_stats,
                                                                 int64_t outer, int64_t R, int64_t inner, int64_t rows_per_chunk,
                                                                 float* __restrict__ dx) {
     const int64_t o = blockIdx.y;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
     const float invR = 1.f / (float)R, invM = 1.f / (float)(outer * R);
     for (int64_t i = threadIdx.x; i < inner; i += blockDim.x) {
-        const float mu = mean[i], is = invstd[i], ga = gamma[i], be = beta[i], q0 = red[i], q1 = red[inner + i];
+        // (`red`: the slices the reduce kernel filled; workgroup (0, 0) leaves the totals - dL/dbeta, dL/dgamma - in its first 2 * inner elements)
+        const float q0 = svnet_slices_total(red, 2 * (int)inner, (int)i), q1 = svnet_slices_total(red, 2 * (int)inner, (int)(inner + i));
+        if (blockIdx.x == 0 && blockIdx.y == 0) { red[i] = q0; red[inner + i] = q1; }
+        const float mu = mean[i], is = invstd[i], ga = gamma[i], be = beta[i];
         const float gx = gmax[o * g_ld + i], gm = gmean[o * g_ld + i] * invR;
         const int am = argmax[o * inner + i];
         const float* p = x + o * R * inner + i;
@@ -555,6 +557,8 @@ extern "C" int svnet_bn_pool_bwd_f32(const float* gmax, const float* gmean, int6
         hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3((unsigned)chunks, (unsigned)outer), dim3(256), 0, st, gmax, gmean, g_ld, argmax, y, mean,
                            invstd, gamma, beta, red, act, slope, train_stats, outer, R, inner, rpc, dy);
         SVNET_CHECK_LAUNCH("bn_pool_bwd_apply_kernel");
+    } else {
+        return svnet_slices_sum_f32(red, 2 * inner, stream);          // (no apply pass: the totals by a kernel of their own)
     }
     return SVNET_OK;
 }

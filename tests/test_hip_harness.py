@@ -277,10 +277,11 @@ def test_conv_bn_relu_rows_matches_the_channel_first_oracle(binary, hip_device):
 
 
 def test_sliced_sums_are_complete_every_time(hip_device):
-    """The grid-wide reductions add into 16 slices and the last workgroup to arrive sums them (csrc/common.h svnet_slices_finish): the sum
-    it leaves must hold EVERY workgroup's share, every time.  (With no-return atomics - acknowledged before they are executed at the
-    memory side - one launch in a few hundred summed a slice that was still missing a share: a 6 % error.)  300 launches per kernel
-    on the conv5-sized tensors of the bench model, each against a float64 torch sum."""
+    """The grid-wide reductions add into 16 slices and the NEXT kernel of the stream sums them (csrc/common.h svnet_slices_total; here
+    svnet_slices_sum_*): the totals must hold EVERY workgroup's share, every time.  (Round 3 summed them in the reducing kernel's last
+    workgroup to arrive; with no-return atomics one launch in a few hundred summed a slice that was still missing a share: a 6 % error.
+    The hand-off is a kernel boundary now.)  300 launches per kernel on the conv5-sized tensors of the bench model, each against a
+    float64 torch sum."""
     from svnet_amd import _ops
     from svnet_amd._ops import _p, _stream, call, _sliced_len
     torch.manual_seed(3)
@@ -299,10 +300,13 @@ def test_sliced_sums_are_complete_every_time(hip_device):
     for it in range(300):
         sv = torch.zeros(_sliced_len(2 * C), dtype=torch.float64, device=hip_device)
         call("svnet_colstats_f64", _p(v), M, C, 1, _p(sv), _stream())
+        call("svnet_slices_sum_f64", _p(sv), 2 * C, _stream())
         sx = torch.zeros(_sliced_len(2 * 512), dtype=torch.float64, device=hip_device)
         call("svnet_colstats_f64", _p(x), M, 512, 0, _p(sx), _stream())
+        call("svnet_slices_sum_f64", _p(sx), 1024, _stream())
         red = torch.zeros(_sliced_len(2 * 512), dtype=torch.float32, device=hip_device)
         call("svnet_bn_act_bwd_reduce_f32", _p(g), _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), M, 512, 0, 0.2, _p(red), _stream())
+        call("svnet_slices_sum_f32", _p(red), 1024, _stream())
         for i, (got, ref) in enumerate(((sv[:2 * C], ref_v), (sx[:1024], ref_x), (red[:1024].double(), ref_r))):
             worst[i] = max(worst[i], float((got - ref).abs().max() / ref.abs().max()))
     assert worst[0] < 1e-6 and worst[1] < 1e-6 and worst[2] < 1e-4, worst

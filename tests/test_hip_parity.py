@@ -406,7 +406,7 @@ def test_graph_feature_coordinate_gradients_match_oracle(mode, hip_device):
                  RTOL, "graph feature coordinate gradients (%s)" % mode)
 
 
-@pytest.mark.parametrize("shape", [(1500, 2044, 512), (2048, 505, 512), (1024, 83, 64), (3000, 1022, 341), (4096, 64, 170)],
+@pytest.mark.parametrize("shape", [(1500, 2044, 512), (2048, 505, 512), (1024, 83, 64), (3000, 1022, 341), (4096, 64, 170), (1100, 300, 600)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_binlinear_matrix_core_path_is_bit_identical(shape, hip_device):
     """svnet_binlinear_i8_fwd_f32 (int8 ternary operands on v_mfma_i32_32x32x32_i8, used for >= 1024 rows) against the XNOR-popcount
@@ -438,9 +438,10 @@ def test_binlinear_matrix_core_path_is_bit_identical(shape, hip_device):
         pl = [torch.full(((M + 63) // 64, K), -1, dtype=torch.int64, device=hip_device) for _ in range(3)]
         if matrix_cores:
             from svnet_amd._ops import _sliced_len
-            sums = torch.zeros(_sliced_len(2 * O), dtype=torch.float64, device=hip_device)       # sliced accumulator: result in the first 2 O
+            sums = torch.zeros(_sliced_len(2 * O), dtype=torch.float64, device=hip_device)       # sliced accumulator: the totals go to the first 2 O
             call("svnet_binlinear_i8_fwd_f32", _p(x), K, _p(beta), _p(w8), _p(sc), _p(bias), M, K, O, _p(y), _p(pl[0]), _p(pl[1]), _p(pl[2]),
                  _p(sums), _stream())
+            call("svnet_slices_sum_f64", _p(sums), 2 * O, _stream())      # (in the product the consuming svnet_bn_finalize_f32 adds the slices up)
         else:
             call("svnet_binlinear_fwd_f32", _p(x), K, _p(beta), _p(ws), _p(wz), _p(sc), _p(bias), M, K, O, _p(y), _p(pl[0]), _p(pl[1]),
                  _p(pl[2]), _stream())
