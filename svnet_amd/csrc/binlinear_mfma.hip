@@ -193,7 +193,7 @@ __global__ __launch_bounds__(1024, 4) void binlinear_i8_fwd_kernel(const float* 
     // workgroup's sums of n and n^2 are exact; sum y = scale*S1 + R*bias, sum y^2 = scale^2*S2 + 2 scale*bias*S1 + R*bias^2 over its R rows,
     // in double, one atomic pair per column and workgroup - the layer's output is not read again for its statistics
     if (col_sums) {
-        long long* red = reinterpret_cast<long long*>(pw);          // [2][OT] (the plane words are consumed: the loop ended on a barrier)
+        long long* red = reinterpret_cast<long long*>(bl_lds);      // [2][OT] <= 8 KiB over the A tile (consumed: the loop ended on a barrier)
         for (int i = tid; i < 2 * OT; i += 1024) red[i] = 0;
         __syncthreads();
 #pragma unroll

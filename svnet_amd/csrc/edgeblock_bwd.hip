@@ -27,7 +27,9 @@ namespace {
 #define ATOMIC_ADD(p, v) do { if (MODE != 1) atomicAdd((p), (v)); else asm volatile("" :: "v"(v)); } while (0)
 
 // Optional phase stopwatch (-DSVNET_PHASE_CLOCK, diagnostic builds only): thread 0 of every workgroup adds the cycles between
-// phase boundaries to debug[8 + phase]; debug must then hold >= 16 entries.
+// phase boundaries to debug[8 + phase]; debug must then hold >= 24 entries.  Marks of the tile kernel: 0 phase A (loads -> dy -> split ->
+// LDS), 1 plane transposition, 5 phase B MFMAs, 6 the barrier behind them, 2 phase B epilogue (STE mask, dbeta, dx tile to LDS),
+// 7 phase C pass 1 (scalar part), 9 passes 2 + 3 (neighbour rows, Vector2Scalar backward), 4 pass 4 (message rows, centre sums).
 #ifdef SVNET_PHASE_CLOCK
 #define PHASE_MARK(i) do { if (threadIdx.x == 0 && d.debug) { const long long t_ = clock64(); \
         atomicAdd(reinterpret_cast<unsigned long long*>(d.debug) + 8 + (i), (unsigned long long)(t_ - ph_t)); ph_t = t_; } } while (0)
@@ -689,8 +691,10 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
         // instructions, too short to cover an L2 round trip, while the epilogue below is 300 - 450 (and phase B's weight fragments are
         // dead by now: the registers are free).  conv4 531 -> 521 us, conv3 330 -> 320; at Os = 32 the epilogue is two column tiles per
         // wave and the early requests only lengthened live ranges (254 -> 276 us): there they stay at the start of phase C.
+        PHASE_MARK(5);   // phase B: MFMAs issued
         if constexpr (NC2 > 0 && NKS >= 4) SVNET_PHASEC_REQUESTS();
         __syncthreads();   // every wave has consumed dnb: dxl may now overwrite the same LDS bytes
+        PHASE_MARK(6);   // phase B: barrier behind the MFMAs
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int ct = cts[q];
@@ -792,6 +796,7 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
             }
             if (cur_p != 0xFFFFFFFFu && s_lane) ATOMIC_ADD(&d.ds_acc[cur_p * (uint32_t)Cs + (uint32_t)lane], cs_sum);
         }
+        PHASE_MARK(7);   // phase C pass 1
         // ---- pass 2: the neighbours' v rows into the (consumed) scalar columns of their tile rows: [3][Cv] at column 0 (3 Cv <= 2 Cs)
 #pragma unroll
         for (int rr = 0; rr < RW; ++rr) {
@@ -827,6 +832,7 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
             dz0 += dpp_get<DPP_ROW_SHR4>(dz0); dz1 += dpp_get<DPP_ROW_SHR4>(dz1); dz2 += dpp_get<DPP_ROW_SHR4>(dz2);
             if (ch == 1 && q < 3) { zs[r * 9 + q * 3 + 0] = dz0; zs[r * 9 + q * 3 + 1] = dz1; zs[r * 9 + q * 3 + 2] = dz2; }
         }
+        PHASE_MARK(9);   // phase C passes 2 + 3
         // ---- pass 4: lanes = elements L of the message row's Vector2Scalar part [dve (3 x Cv) | dz (9)]; centre sums [dv | dz] per point
         {
             const int nout = n3 + 9;

@@ -2,6 +2,10 @@
 gpurun_out/, runs one fused backward per layer shape and prints the mean cycles each workgroup spent per phase."""
 import os, subprocess, sys, shutil
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) == 1 and os.path.exists(os.path.join(root, "_ab", "libphase.so")):
+    # built beforehand: make -C svnet_amd/csrc BUILD=_build_phase OUT=../../_ab/libphase.so EXTRA=-DSVNET_PHASE_CLOCK
+    env = dict(os.environ, SVNET_HIP_LIB=os.path.join(root, "_ab", "libphase.so"))
+    sys.exit(subprocess.call([sys.executable, __file__, "run"], env=env))
 if len(sys.argv) == 1:
     out = os.path.join(root, "gpurun_out", "phase_lib")
     os.makedirs(out, exist_ok=True)
@@ -25,17 +29,21 @@ _lib.LIB_PATH = os.environ["SVNET_HIP_LIB"]
 from svnet_amd.models.sv_layers import SVBlock
 from svnet_amd.models.utils.sv_util import get_graph_feature_sv, svpool
 config.FUSE_EDGE_BLOCKS = True
-names = ["A", "transpose", "B", "(C1, merged into C)", "C"]
+names = {0: "A", 1: "transpose", 5: "B_mfma", 6: "B_barrier", 2: "B_epilogue", 7: "C_pass1", 9: "C_pass23", 4: "C_pass4", 3: "C1_old"}
+order = [0, 1, 5, 6, 2, 7, 9, 4]
 for (Cs, Cv, Os, Ov) in [(32, 10, 32, 10), (32, 10, 64, 21), (64, 21, 128, 42)]:
     with contextlib.redirect_stdout(io.StringIO()):
         blk = SVBlock((2 * Cs, 2 * Cv), (Os, Ov), binary=True).cuda().train()
     s = torch.randn(32, 1024, Cs, device="cuda", requires_grad=True)
     v = torch.randn(32, 1024, 3, Cv, device="cuda", requires_grad=True)
     for it in range(3):
-        _ops.DEBUG_BUFFER = torch.zeros(16, dtype=torch.int64, device="cuda")
+        _ops.DEBUG_BUFFER = torch.zeros(32, dtype=torch.int64, device="cuda")
         so, vo = svpool(blk(get_graph_feature_sv((s, v), k=20)))
         (so.sum() + vo.sum()).backward()
         torch.cuda.synchronize()
-    cyc = _ops.DEBUG_BUFFER.cpu().tolist()[8:13]
+    cyc = _ops.DEBUG_BUFFER.cpu().tolist()
     tiles = 32 * 1024 * 20 // 32
-    print("Os=%d" % Os, " ".join("%s=%d" % (n, c // tiles) for n, c in zip(names, cyc)), "cycles per workgroup (clock64 ticks)", flush=True)
+    per = {i: cyc[8 + i] / tiles for i in order}
+    tot = sum(per.values())
+    print("Os=%d Cs=%d Cv=%d: %d clock64 ticks (100 MHz x ?) per workgroup in all: " % (Os, Cs, Cv, tot)
+          + " ".join("%s=%d (%.0f%%)" % (names[i], per[i], 100.0 * per[i] / tot) for i in order), flush=True)
