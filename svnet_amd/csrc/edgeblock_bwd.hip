@@ -27,16 +27,24 @@ namespace {
 #define ATOMIC_ADD(p, v) do { if (MODE != 1) atomicAdd((p), (v)); else asm volatile("" :: "v"(v)); } while (0)
 
 // Optional phase stopwatch (-DSVNET_PHASE_CLOCK, diagnostic builds only): thread 0 of every workgroup adds the cycles between
-// phase boundaries to debug[8 + phase]; debug must then hold >= 24 entries.  Marks of the tile kernel: 0 phase A (loads -> dy -> split ->
+// phase boundaries to debug[8 + phase]; debug must then hold >= 8 + 256 * 16 entries (256 slices, summed by the reader: 20 480 workgroups adding to the SAME 16 addresses took 1.3 ms).  Marks of the tile kernel: 0 phase A (loads -> dy -> split ->
 // LDS), 1 plane transposition, 5 phase B MFMAs, 6 the barrier behind them, 2 phase B epilogue (STE mask, dbeta, dx tile to LDS),
 // 7 phase C pass 1 (scalar part), 9 passes 2 + 3 (neighbour rows, Vector2Scalar backward), 4 pass 4 (message rows, centre sums).
 #ifdef SVNET_PHASE_CLOCK
-#define PHASE_MARK(i) do { if (threadIdx.x == 0 && d.debug) { const long long t_ = clock64(); \
-        atomicAdd(reinterpret_cast<unsigned long long*>(d.debug) + 8 + (i), (unsigned long long)(t_ - ph_t)); ph_t = t_; } } while (0)
-#define PHASE_INIT() long long ph_t = clock64()
+// (the deltas are parked in LDS and added to debug[] in ONE go when the workgroup ends: an atomic per mark sat in the wave's vmcnt queue
+//  in front of the next phase's loads - which retire in order - and 20 480 workgroups adding to the same eight addresses made each one
+//  slow: the first table of this round charged that wait to whatever phase came next)
+#define PHASE_MARK(i) do { if (threadIdx.x == 0) { const long long t_ = clock64(); ph_acc[i] += (unsigned long long)(t_ - ph_t); ph_t = t_; } } while (0)
+#define PHASE_INIT() __shared__ unsigned long long ph_acc[16]; long long ph_t = 0, ph_t0 = 0, ph_w0 = 0; \
+    if (threadIdx.x == 0) { for (int i_ = 0; i_ < 16; ++i_) ph_acc[i_] = 0ull; ph_t = ph_t0 = clock64(); ph_w0 = wall_clock64(); }
+/* [14] = the workgroup's lifetime in clock64 ticks, [15] = in wall_clock64 ticks (constant 100 MHz): their ratio calibrates the tick */
+#define PHASE_FLUSH() do { if (threadIdx.x == 0 && d.debug) { ph_acc[14] = (unsigned long long)(clock64() - ph_t0); \
+        ph_acc[15] = (unsigned long long)(wall_clock64() - ph_w0); for (int i_ = 0; i_ < 16; ++i_) if (ph_acc[i_]) \
+        atomicAdd(reinterpret_cast<unsigned long long*>(d.debug) + 8 + 16 * (blockIdx.x & 255) + i_, ph_acc[i_]); } } while (0)   /* 256 slices of 16: debug holds >= 8 + 4096 entries */
 #else
 #define PHASE_MARK(i) do { } while (0)
 #define PHASE_INIT() do { } while (0)
+#define PHASE_FLUSH() do { } while (0)
 #endif
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -467,8 +475,13 @@ _Pragma("unroll") \
 // MODE: 0 = product; 1..3 = timing-only ablations (SVNET_BWD_MODE), wrong results.  NKS = k-steps of phase B (Os <= 16*NKS)
 // NC2: 0 = phase C as one edge per wave iteration (lanes = channels); > 0 = the lanes = (edge, axis) form of phase C for 2 Cv <= NC2
 // (20: Cv <= 10 - five channel pairs per lane; 24: Cv <= 12; 44: Cv <= 21 - a neighbour's [3][Cv] row fits one 64-lane load and 11 channel pairs per lane; 48: Cv <= 24)
+// (One tile per workgroup.  A loop over two tiles per workgroup - so that the drain of a tile's last atomics and the next workgroup's
+//  prologue lie under the next tile's phase A - was built this round and not kept: whatever form the loop took (by-value descriptor,
+//  descriptor re-read through an opaque kernarg offset) the allocator kept 56 .. 382 registers live across the back edge and spilled
+//  them; as a non-inlined function the callee-saved registers went to scratch twice per tile.)
 template <int MODE, int NKS, int NC2 = 0>
 __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_bwd_desc d) {
+    const uint32_t tile_lin = blockIdx.x;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Cs = d.Cs, Cv = d.Cv, Os = d.Os;
     const int DNB = dn_stride(Os);
@@ -486,7 +499,7 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
     // XCD-aware tile order: workgroups b and b+8 share an XCD (round-robin dispatch), so give XCD x the clouds
     // x, x+8, ... one after the other: a cloud's point tables (~1.6 MB) then live in that XCD's 4 MiB L2
     // (32-bit arithmetic throughout: E < 2^31 is checked on the host)
-    uint32_t tile = blockIdx.x;
+    uint32_t tile = tile_lin;
     const uint32_t nk = (uint32_t)d.N * (uint32_t)d.k;
     const uint32_t tpc = nk / TE;                                    // tiles per cloud
     if ((d.B & 7) == 0 && tpc * TE == nk) {
@@ -510,7 +523,9 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
     const int cm = diff_lane ? lane : lane - Cv;
     // neighbour ids of this wave's 8 edge rows for phase C2 (lane rr holds idx[ew + rr]): requested now, consumed through
     // v_readlane, so the row gathers of phase C2 never wait on a load of their own index
-    const int jv8 = (int)d.idx[min(ew + (lane & 7), E - 1)];
+    // (the LOW dword of the int64 id only: with a 64-bit load the allocator recycled the dead high register at once, and the write-after-
+    //  write hazard cost a full `s_waitcnt vmcnt(0)` - an HBM round trip - before any other load of the tile had been issued)
+    const int jv8 = reinterpret_cast<const int*>(d.idx)[2 * min(ew + (lane & 7), E - 1)];
 
     // The 320 fused columns are 5 words x 64, of which only Cs / Cs / 2Cv / 2Cv / 2Cv are in use: 32-column tiles that lie
     // entirely in the padding (5 of 10 for the Cs = 32, Cv = 10 layers) are skipped by phase B, and the used ones are dealt
@@ -546,16 +561,29 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
     } while (0)
     constexpr bool HOIST_B = NKS <= 4;
     if (HOIST_B) SVNET_LOAD_BFR(0);
+    // the gate path's per-cloud constants of phase C's scalar pass (lane = scalar channel): requested HERE.  Loaded where they are used
+    // - first thing in pass 1, behind the ~20 gather requests of phase C that are still in flight (vmcnt retires in order) - they made
+    // that pass wait out the whole gather: 19 % (conv4) to 42 % (conv2) of a workgroup's time (phase clocks, profiles/r04_tile_phases.txt)
+    float gc_pre0 = 0.f, gc_pre1 = 0.f;
+    if constexpr (NC2 > 0) {
+        const int sl_ = min(lane, Cs - 1);
+        gc_pre0 = d.gconst[tp.b0 * 2u * (uint32_t)Cs + sl_];
+        gc_pre1 = d.gconst[tp.b0 * 2u * (uint32_t)Cs + Cs + sl_];
+    }
 
     // ================= phase A: dL/dy_pre of the tile's 32 x Os edge-channels from the saved integer sums =========
     //   dy_pre = cs*(g - m1 - xhat*m2), xhat = (scale*n - mean)*invstd, g = gy[p,o] on the pooled edge, else 0
     //          = cs*g - (alpha + beta*n)
     {
-        // ternary / STE planes of the tile: [e][plane][word] in HBM -> [plane][row][word] in LDS
-        for (int item = tid; item < TE * 3 * NW; item += 256) {
-            const int r = item / (3 * NW), q = item - r * (3 * NW);
-            const int plane = q / NW, w = q - plane * NW;
-            pl[(plane * TE + r) * NW + w] = (e0 + r < E) ? d.planes[(e0 + r) * (3 * NW) + q] : 0ull;
+        // ternary / STE planes of the tile: [e][plane][word] in HBM -> [plane][row][word] in LDS.  REQUESTED here (two words per thread),
+        // stored behind the other requests of phase A: as a load -> store loop the second word was requested after the first had arrived
+        static_assert(TE * 3 * NW <= 512, "two plane words per thread");
+        uint64_t plw[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int item = min(tid + 256 * u, TE * 3 * NW - 1);
+            const int r = item / (3 * NW);
+            plw[u] = d.planes[min(e0 + r, E - 1) * (3 * NW) + (item - r * (3 * NW))];
         }
         // this thread's edge-channel quads (<= 4: Os <= 128): their loads go out before the barrier, with the constants'
         const int O4 = Os >> 2;
@@ -571,7 +599,9 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
         const float4 sc = *reinterpret_cast<const float4*>(chc + 3 * Os + o4c);
         const float4 ps = *reinterpret_cast<const float4*>(chc + 4 * Os + o4c);
         constexpr int NI = NKS / 2;       // TE * (Os / 4) / 256 quads per thread
-        short4 n4[NI]; float4 gy4[NI]; uchar4 smx[NI], smn[NI]; int tt[NI];
+        // (n and the pooled slots stay PACKED until they are used: as short4 / uchar4 they were unpacked right behind their loads - a
+        //  wait per quad, four dependent round trips per tile - profiles/r04_tile_phases.txt)
+        uint2 n4[NI]; float4 gy4[NI]; uint32_t smx[NI], smn[NI]; int tt[NI];
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
             const int item = it * 256 + tid;
@@ -582,13 +612,25 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
                 const uint32_t n_ = (uint32_t)(tp.t0 + r), dq_ = small_div(n_, tp.kmagic);
                 const int64_t gp = (int64_t)(tp.gp0 + dq_);
                 tt[it] = (int)(n_ - dq_ * (uint32_t)k);
-                n4[it] = *reinterpret_cast<const short4*>(d.n16 + e * Os + o4);
+                n4[it] = *reinterpret_cast<const uint2*>(d.n16 + e * Os + o4);
                 gy4[it] = *reinterpret_cast<const float4*>(d.gy + gp * Os + o4);
-                smx[it] = *reinterpret_cast<const uchar4*>(d.slot_max + gp * Os + o4);
-                smn[it] = *reinterpret_cast<const uchar4*>(d.slot_min + gp * Os + o4);
+                smx[it] = *reinterpret_cast<const uint32_t*>(d.slot_max + gp * Os + o4);
+                smn[it] = *reinterpret_cast<const uint32_t*>(d.slot_min + gp * Os + o4);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);       // every request of phase A is out before the first wait
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int item = tid + 256 * u;
+            if (item < TE * 3 * NW) {
+                const int r = item / (3 * NW), q = item - r * (3 * NW);
+                const int plane = q / NW, w = q - plane * NW;
+                pl[(plane * TE + r) * NW + w] = (e0 + r < E) ? plw[u] : 0ull;
+            }
+        }
+        PHASE_MARK(11);   // phase A: requests issued
         __syncthreads();
+        PHASE_MARK(12);   // phase A: planes in LDS (first barrier)
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
             const int item = it * 256 + tid;
@@ -602,15 +644,18 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
                 for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(dnb + (p * TE + r) * DNB + 8) = make_uint4(0u, 0u, 0u, 0u);
             }
             if (t >= 0) {
-                const float g0 = ((ps.x != 0.f ? smx[it].x : smn[it].x) == t) ? gy4[it].x : 0.f;
-                const float g1 = ((ps.y != 0.f ? smx[it].y : smn[it].y) == t) ? gy4[it].y : 0.f;
-                const float g2 = ((ps.z != 0.f ? smx[it].z : smn[it].z) == t) ? gy4[it].z : 0.f;
-                const float g3 = ((ps.w != 0.f ? smx[it].w : smn[it].w) == t) ? gy4[it].w : 0.f;
+                const uint32_t sx = smx[it], sn = smn[it];
+                const float g0 = ((int)((ps.x != 0.f ? sx : sn) & 0xFFu) == t) ? gy4[it].x : 0.f;
+                const float g1 = ((int)(((ps.y != 0.f ? sx : sn) >> 8) & 0xFFu) == t) ? gy4[it].y : 0.f;
+                const float g2 = ((int)(((ps.z != 0.f ? sx : sn) >> 16) & 0xFFu) == t) ? gy4[it].z : 0.f;
+                const float g3 = ((int)((ps.w != 0.f ? sx : sn) >> 24) == t) ? gy4[it].w : 0.f;
+                const float n0 = (float)(short)(n4[it].x & 0xFFFFu), n1 = (float)((int)n4[it].x >> 16);
+                const float n2 = (float)(short)(n4[it].y & 0xFFFFu), n3 = (float)((int)n4[it].y >> 16);
                 float4 dy;
-                dy.x = cs.x * g0 - (al.x + be.x * (float)n4[it].x);
-                dy.y = cs.y * g1 - (al.y + be.y * (float)n4[it].y);
-                dy.z = cs.z * g2 - (al.z + be.z * (float)n4[it].z);
-                dy.w = cs.w * g3 - (al.w + be.w * (float)n4[it].w);
+                dy.x = cs.x * g0 - (al.x + be.x * n0);
+                dy.y = cs.y * g1 - (al.y + be.y * n1);
+                dy.z = cs.z * g2 - (al.z + be.z * n2);
+                dy.w = cs.w * g3 - (al.w + be.w * n3);
                 if (d.dn_out) *reinterpret_cast<float4*>(d.dn_out + e * Os + o4) = dy;   // (optional: svnet_edgeblock_wgrad_f32 recomputes it)
                 dn = make_float4(dy.x * sc.x, dy.y * sc.y, dy.z * sc.z, dy.w * sc.w);
             }
@@ -625,7 +670,7 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
     }
     __syncthreads();
     PHASE_MARK(0);   // phase A
-    if (MODE == 2) return;
+    if (MODE == 2) { PHASE_FLUSH(); return; }
 
     // ---- ternary planes of this tile -> row-sliced 32-bit halves (rows = the tile's 32 edges)
     {
@@ -717,13 +762,13 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
                     csum += v;
                 }
                 const float other = __uint_as_float(lane_half_swap(__float_as_uint(csum)));
-                if (h == 0 && in_use) { const float t = csum + other; if (t != 0.f) ATOMIC_ADD(&d.dbeta_perm[(blockIdx.x & (SVNET_DBETA_SLICES - 1)) * NCOL + col], t); }
+                if (h == 0 && in_use) { const float t = csum + other; if (t != 0.f) ATOMIC_ADD(&d.dbeta_perm[(tile_lin & (SVNET_DBETA_SLICES - 1)) * NCOL + col], t); }
             }
         }
     }
     __syncthreads();
     PHASE_MARK(2);   // phase B
-    if (MODE == 3) return;
+    if (MODE == 3) { PHASE_FLUSH(); return; }
 
     if constexpr (NC2 > 0) {
         // ================= phase C, 8 rows per wave, every global access a whole row =================
@@ -768,6 +813,7 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
         const float zj0 = pc_zj[0], zj1 = pc_zj[1], zj2 = pc_zj[2];
         const float zi0 = pc_zi[0], zi1 = pc_zi[1], zi2 = pc_zi[2], zi3 = pc_zi[3], zi4 = pc_zi[4], zi5 = pc_zi[5];
 
+        PHASE_MARK(10);   // phase C: set-up (cursor, requests of the narrow layers)
         // ---- pass 1: scalar part, lanes = scalar channels
         {
             const bool s_lane = lane < Cs;
@@ -783,7 +829,8 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
                     cs_sum = 0.f;
                     if (c2.b != cur_b) {
                         cur_b = c2.b;
-                        g0c = d.gconst[cur_b * 2u * (uint32_t)Cs + sl]; g1c = d.gconst[cur_b * 2u * (uint32_t)Cs + Cs + sl];
+                        if (cur_b == tp.b0) { g0c = gc_pre0; g1c = gc_pre1; }      // (the tile's first cloud: requested at the kernel's start)
+                        else { g0c = d.gconst[cur_b * 2u * (uint32_t)Cs + sl]; g1c = d.gconst[cur_b * 2u * (uint32_t)Cs + Cs + sl]; }
                     }
                 }
                 const float* row = dxl + (row0 + rr) * DXS;
@@ -871,6 +918,7 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
             }
         }
         PHASE_MARK(4);
+        PHASE_FLUSH();
         return;
     }
 
@@ -998,6 +1046,7 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
 #undef SVNET_LOAD_BFR
     }
     PHASE_MARK(4);   // phase C2 (wave 0 of the workgroup)
+    PHASE_FLUSH();
 }
 
 }  // namespace
