@@ -142,12 +142,30 @@ __device__ __forceinline__ void edgeblock_fwd_body(const FwdArgs& fa, const floa
     // Neighbour ids: lane t of one coalesced load holds idx[p][t] (k <= 64) and v_readlane hands it to the scalar unit, so the
     // gathers of an edge never wait on a load of their own index; the next point's ids are requested a whole point ahead.
     const int lk = min(lane, k - 1);
-    int jv_next = (p_begin < p_end) ? (int)tidx[(b * d.N + p_begin) * k + lk] : 0;
+    int jv_next = (p_begin < p_end) ? reinterpret_cast<const int*>(tidx)[2 * ((b * d.N + p_begin) * k + lk)] : 0;    // (low dword of the int64 id)
     for (int p = p_begin; p < p_end; ++p) {
         const int64_t gp = b * d.N + p;
         const int jv = jv_next;
-        if (p + 1 < p_end) jv_next = (int)tidx[(gp + 1) * k + lk];
-        const float s_i = s_lane ? ts[gp * Cs + min(lane, Cs - 1)] : 0.f;
+        if (p + 1 < p_end) jv_next = reinterpret_cast<const int*>(tidx)[2 * ((gp + 1) * k + lk)];
+        // the point's OWN operands: every load unconditional (clamped lane index, masked where it is used) and requested before the first
+        // use.  With exec-masked lanes each `cond ? load : 0` became a branch around its load, every axis its own basic block ending in
+        // `s_waitcnt vmcnt(0)` for the difference it forms at once: four dependent L2 round trips at the start of every point.
+        const float s_raw = ts[gp * Cs + min(lane, Cs - 1)];
+        float vi_raw[3], zr_raw[3][6], tu_raw[3][2];
+        {
+            const int cmc = v2_lane ? cm : 0, loc = min(lane, Ov - 1);
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd) {
+                vi_raw[dd] = tv[(gp * 3 + dd) * Cv + cmc];
+                const float* zrow = tzz + (gp * 3 + dd) * 6;
+#pragma unroll
+                for (int jz = 0; jz < 6; ++jz) zr_raw[dd][jz] = zrow[jz];
+                tu_raw[dd][0] = tut[(gp * 3 + dd) * 2 * Ov + Ov + loc];
+                tu_raw[dd][1] = tut[(gp * 3 + dd) * 2 * Ov + loc];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float s_i = s_lane ? s_raw : 0.f;
         gs_cen += s_i;
         const float tc = s_i + bc;
         const uint64_t csg = __ballot(s_lane && tc > 0.f), cnz = __ballot(s_lane && tc != 0.f);
@@ -159,11 +177,10 @@ __device__ __forceinline__ void edgeblock_fwd_body(const FwdArgs& fa, const floa
         float vi[3], zi[3][3], ub[3];
 #pragma unroll
         for (int dd = 0; dd < 3; ++dd) {
-            vi[dd] = v2_lane ? tv[(gp * 3 + dd) * Cv + cm] : 0.f;
-            const float* zrow = tzz + (gp * 3 + dd) * 6;
+            vi[dd] = v2_lane ? vi_raw[dd] : 0.f;
 #pragma unroll
-            for (int jz = 0; jz < 3; ++jz) zi[dd][jz] = zrow[3 + jz] - zrow[jz];  // Zq_i - Zp_i
-            ub[dd] = o_lane ? tut[(gp * 3 + dd) * 2 * Ov + Ov + lane] - tut[(gp * 3 + dd) * 2 * Ov + lane] : 0.f;  // T_i - U_i
+            for (int jz = 0; jz < 3; ++jz) zi[dd][jz] = zr_raw[dd][3 + jz] - zr_raw[dd][jz];  // Zq_i - Zp_i
+            ub[dd] = o_lane ? tu_raw[dd][0] - tu_raw[dd][1] : 0.f;  // T_i - U_i
         }
         int nmax[OP], nmin[OP], smax[OP], smin[OP];
 #pragma unroll
@@ -384,7 +401,7 @@ __global__ __launch_bounds__(256, 4) void edgeblock_fwd2_kernel(FwdArgs fa) {
     float gs_diff = 0.f, gs_cen = 0.f;
 
     const int lk = min(lane, k - 1);
-    int jv_next = (p_begin < p_end) ? (int)tidx[(b * d.N + p_begin) * k + lk] : 0;
+    int jv_next = (p_begin < p_end) ? reinterpret_cast<const int*>(tidx)[2 * ((b * d.N + p_begin) * k + lk)] : 0;    // (low dword of the int64 id)
     const uint32_t ls = (uint32_t)min(l, Cs - 1), ldv = (uint32_t)min(l, Cv - 1), lo = (uint32_t)min(l, Ov - 1);
     const uint32_t uCs = (uint32_t)Cs, uCv = (uint32_t)Cv, uOv = (uint32_t)Ov;
     const uint32_t cloud0 = (uint32_t)(b * d.N);
@@ -392,8 +409,24 @@ __global__ __launch_bounds__(256, 4) void edgeblock_fwd2_kernel(FwdArgs fa) {
     for (int p = p_begin; p < p_end; ++p) {
         const int64_t gp = b * d.N + p;
         const int jv = jv_next;
-        if (p + 1 < p_end) jv_next = (int)tidx[(gp + 1) * k + lk];
-        const float s_i = s_lane ? ts[gp * Cs + ls] : 0.f;
+        if (p + 1 < p_end) jv_next = reinterpret_cast<const int*>(tidx)[2 * ((gp + 1) * k + lk)];
+        // (the point's own operands: unconditional, clamped loads requested before their first use - see edgeblock_fwd_kernel)
+        const float s_raw = ts[gp * Cs + ls];
+        float vi_raw[3], zr_raw[3][6], tu_raw[3][2];
+        {
+            const int cmc = v2_lane ? cm : 0;
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd) {
+                vi_raw[dd] = tv[(gp * 3 + dd) * Cv + cmc];
+                const float* zrow = tzz + (gp * 3 + dd) * 6;
+#pragma unroll
+                for (int jz = 0; jz < 6; ++jz) zr_raw[dd][jz] = zrow[jz];
+                tu_raw[dd][0] = tut[(gp * 3 + dd) * 2 * Ov + Ov + (int)lo];
+                tu_raw[dd][1] = tut[(gp * 3 + dd) * 2 * Ov + (int)lo];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float s_i = s_lane ? s_raw : 0.f;
         if (!hi) gs_cen += s_i;
         const float tc = s_i + bc;
         const uint64_t csg = __ballot(s_lane && tc > 0.f), cnz = __ballot(s_lane && tc != 0.f);     // both halves identical
@@ -405,11 +438,10 @@ __global__ __launch_bounds__(256, 4) void edgeblock_fwd2_kernel(FwdArgs fa) {
         float vi[3], zi[3][3], ub[3];
 #pragma unroll
         for (int dd = 0; dd < 3; ++dd) {
-            vi[dd] = v2_lane ? tv[(gp * 3 + dd) * Cv + cm] : 0.f;
-            const float* zrow = tzz + (gp * 3 + dd) * 6;
+            vi[dd] = v2_lane ? vi_raw[dd] : 0.f;
 #pragma unroll
-            for (int jz = 0; jz < 3; ++jz) zi[dd][jz] = zrow[3 + jz] - zrow[jz];  // Zq_i - Zp_i
-            ub[dd] = o_lane ? tut[(gp * 3 + dd) * 2 * Ov + Ov + l] - tut[(gp * 3 + dd) * 2 * Ov + l] : 0.f;  // T_i - U_i
+            for (int jz = 0; jz < 3; ++jz) zi[dd][jz] = zr_raw[dd][3 + jz] - zr_raw[dd][jz];  // Zq_i - Zp_i
+            ub[dd] = o_lane ? tu_raw[dd][0] - tu_raw[dd][1] : 0.f;  // T_i - U_i
         }
         int nmax[OP2], nmin[OP2], smax[OP2], smin[OP2];
 #pragma unroll
