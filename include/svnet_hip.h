@@ -45,9 +45,9 @@ int svnet_slices_sum_f64(double* buf, int64_t L, void* stream);
 
 /* ABI version = 100 * round-of-change + serial.  It changes whenever an entry point gains / loses an argument or a caller-owned buffer
  * changes its required length (200: sliced accumulators, SVNET_SLICED_LEN; 400: this header; 401: the totals of a sliced accumulator are
- * written by its consumer, svnet_slices_sum_*).  svnet_version() returns the value the
+ * written by its consumer, svnet_slices_sum_*; 402: GX of svnet_v2s_bwd_*, gw of svnet_xyzblock_bwd_f32 and col_sum of svnet_gemm_f32 are sliced accumulators).  svnet_version() returns the value the
  * library was BUILT with: a caller compiled against another header must refuse to run (svnet_amd/_lib.py does).                   */
-#define SVNET_ABI_VERSION 401
+#define SVNET_ABI_VERSION 402
 int svnet_version(void);
 const char* svnet_last_error(void);
 
@@ -96,8 +96,9 @@ int svnet_edge_diffcat_bwd_f32(const float* d_out, const int64_t* idx, int idx_i
  *   - mask: STE mask of the output, sliced over the output rows i with W = N columns.
  * b_exact != 0 promises that every B value is exactly representable in bf16 (sign weights: -1, 0, +1), which
  * lets the tall-and-skinny product run on bf16 MFMA with an exact 3-way split of A.
- * Epilogue, in this order: *alpha, *col_scale[j], +bias[j], *mask(i,j), then col_sum[j] += sum_i C(i,j) (float
- * atomics, caller zero-fills), then store (or accumulate when accumulate != 0).                                */
+ * Epilogue, in this order: *alpha, *col_scale[j], +bias[j], *mask(i,j), then col_sum[j] += sum_i C(i,j) (float atomics into
+ * the slices of a SLICED accumulator of N floats, SVNET_SLICED_LEN(N): caller zero-fills, totals by svnet_slices_sum_f32), then
+ * store (or accumulate when accumulate != 0).                                                                 */
 typedef struct svnet_gemm_desc {
     int64_t M, N, K;
     const float* A; int64_t a_rs, a_cs;
@@ -314,7 +315,8 @@ int svnet_xyzblock_apply_f32(const float* y_max, const float* y_min, const float
                              float* v_out, float* s_cat, int64_t s_ld, float* v_cat, int64_t v_ld /* as svnet_edgeblock_apply_f32 */,
                              void* stream);
 /* Backward: the coordinates need no gradient, so the edge pass only accumulates parameter gradients
- * gw = [dW1 (Os*12) | dW2 (Ov*2) | dW0 (6) | dWz (6)] (float atomics, caller zero-fills).  bcoef comes from
+ * gw = [dW1 (Os*12) | dW2 (Ov*2) | dW0 (6) | dWz (6)]: a SLICED accumulator of GW = Os*6nc + Ov*nc + 6nc floats (SVNET_SLICED_LEN(GW),
+ * caller zero-fills, totals by svnet_slices_sum_f32).  bcoef comes from
  * svnet_edgeblock_bwd_coeffs_f32 (same coefficient layout); gconst [B,6] = dL/d(gate input) / (N*k).             */
 int svnet_xyzblock_bwd_prelude_f32(const float* gs, const float* gv, const float* y_max, const float* y_min, const float* mv,
                                    const float* mvn, const float* coef, const float* gate, int64_t P, int64_t N, int64_t Os,
@@ -348,7 +350,8 @@ int svnet_edgeblock_wgrad_f32(const int16_t* n16, const uint8_t* slot_max, const
 int svnet_v2s_fwd_f32(const float* v, const float* w_eff, int64_t M, int64_t C, int64_t J, float* s, float* z_out,
                       void* stream);
 /* ds: [M,C*J]; dz_in: optional gradient arriving at z ([M,3,J]); dv: [M,3,C] (written);
- * GX: [J,C] accumulated with atomics (caller zero-fills): GX[j,c] = sum_m sum_i dz[m,i,j] v[m,i,c].  */
+ * GX: a SLICED accumulator of J*C floats (SVNET_SLICED_LEN(J*C), caller zero-fills; totals by svnet_slices_sum_f32):
+ * GX[j,c] = sum_m sum_i dz[m,i,j] v[m,i,c].  */
 int svnet_v2s_bwd_f32(const float* v, const float* w_eff, const float* ds, const float* dz_in, int64_t M, int64_t C,
                       int64_t J, float* dv, float* GX, void* stream);
 /* cat[pre, Vector2Scalar(v)] written in place (sv_layers.py:187-188: the input of an SVBlock's linear1): out [M, out_ld] rows =

@@ -569,14 +569,15 @@ class BinLinear(torch.autograd.Function):
                 dW, dsc = _binweight_grad(GX, W, sc, O, K, ctx.training)
                 dW, dsc = dW.view(wshape), dsc.view(sshape)
         if need_x:
-            dbeta = _zeros((K,), torch.float32, dev)
+            dbuf = _zeros((_sliced_len(K),), torch.float32, dev)        # sliced accumulator of the column sums (dL/dbeta)
             if ctx.training:
                 dx = torch.empty((M, K), dtype=torch.float32, device=dev)
-                gemm(M, K, O, A=g2, a_rs=O, a_cs=1, a_scale=sc, B=w_b, b_rs=K, b_cs=1, b_exact=True, C=dx, ldc=K, mask=x_ste, col_sum=dbeta)
+                gemm(M, K, O, A=g2, a_rs=O, a_cs=1, a_scale=sc, B=w_b, b_rs=K, b_cs=1, b_exact=True, C=dx, ldc=K, mask=x_ste, col_sum=dbuf)
+                call("svnet_slices_sum_f32", _p(dbuf), K, _stream())
             else:   # eval: bare sign() has zero gradient (sv_layers.py:38-39)
                 dx = torch.zeros((M, K), dtype=torch.float32, device=dev)
             dx = dx.view(xshape)
-            dbeta = dbeta.view(bshape)
+            dbeta = dbuf[:K].view(bshape)
         beside.join(dW, dsc)
         if has_bias and ctx.needs_input_grad[4]:
             dbias = pool_raw(g2, 1, M, O, 1)[0].view(O) * float(M)
@@ -699,8 +700,10 @@ class V2S(torch.autograd.Function):
         gs2 = torch.zeros((M, C * J), dtype=torch.float32, device=v3.device) if gs is None else _f32c(gs).reshape(M, C * J)
         gz2 = None if gz is None else _f32c(gz).reshape(M, 3, J)
         dv = torch.empty_like(v3)
-        GX = _zeros((J, C), torch.float32, v3.device)
-        call("svnet_v2s_bwd_f32", _p(v3), _p(w_eff), _p(gs2), _p(gz2), M, C, J, _p(dv), _p(GX), _stream())
+        gxb = _zeros((_sliced_len(J * C),), torch.float32, v3.device)      # sliced accumulator: 2 048 workgroups add to it
+        call("svnet_v2s_bwd_f32", _p(v3), _p(w_eff), _p(gs2), _p(gz2), M, C, J, _p(dv), _p(gxb), _stream())
+        call("svnet_slices_sum_f32", _p(gxb), J * C, _stream())
+        GX = gxb[:J * C].view(J, C)
         dW, dsc = GX, None
         if sc is not None:
             dW, dsc = _binweight_grad(GX, W, sc, J, C, ctx.training)
@@ -768,8 +771,10 @@ class V2SCat(torch.autograd.Function):
             else:
                 ds = g2[:, :Cs].reshape(sshape)          # (a strided view: its consumers read it in place)
         dv = torch.empty_like(v3)
-        GX = _zeros((J, C), torch.float32, v3.device)
-        call("svnet_v2s_bwd_ld_f32", _p(v3), _p(w_eff), _p(g2[:, Cs:]), Cs + C * J, None, M, C, J, _p(dv), _p(GX), _stream())
+        gxb = _zeros((_sliced_len(J * C),), torch.float32, v3.device)
+        call("svnet_v2s_bwd_ld_f32", _p(v3), _p(w_eff), _p(g2[:, Cs:]), Cs + C * J, None, M, C, J, _p(dv), _p(gxb), _stream())
+        call("svnet_slices_sum_f32", _p(gxb), J * C, _stream())
+        GX = gxb[:J * C].view(J, C)
         dW, dsc = GX, None
         if sc is not None:
             dW, dsc = _binweight_grad(GX, W, sc, J, C, ctx.training)
@@ -1688,8 +1693,9 @@ class XyzBlock(torch.autograd.Function):
         gy = torch.empty((P, Os), **f32)
         H = Wg0.shape[0]
         F = torch.float32
+        GW = Os * NF + Ov * NC + NF
         red, redv, dgate, dWg0, dWg2, gw = _zeros_pool(dev, ((RED_SLICES * 2 * Os,), F), ((RED_SLICES * 2 * Ov,), F), ((B, Ov), F), ((H, NG), F), ((Ov, H), F),
-                                                       ((Os * NF + Ov * NC + NF,), F))
+                                                       ((_sliced_len(GW),), F))        # gw: sliced accumulator
         call("svnet_xyzblock_bwd_prelude_f32", _p(gs), _p(gv), _p(y_max), _p(y_min), _p(mv), _p(mvn), _p(coef), _p(gate), P, N, Os, Ov, 0.2,
              _p(gy), _p(red), _p(redv), _p(dgate), _p(gs2), gs2_ld, _p(gv2), gv2_ld, _p(gv_sum), _stream())
         if gv_sum is not None:
@@ -1712,6 +1718,7 @@ class XyzBlock(torch.autograd.Function):
         d.gy, d.gv, d.gconst, d.gw = _p(gy), _p(gv), _p(gconst), _p(gw)
         d.nc = NC
         call("svnet_xyzblock_bwd_f32", ctypes.byref(d), _stream())
+        call("svnet_slices_sum_f32", _p(gw), GW, _stream())
         o = Os * NF
         dW1 = gw[:o].view(Os, NF)
         dW2 = gw[o:o + Ov * NC].view(Ov, NC)

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs ga) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s += red[r * 64 + tid];
             const int64_t gj = j0 + tid;
-            if (gj < d.N) atomicAdd(&d.col_sum[gj], s);
+            if (gj < d.N) atomicAdd(&svnet_slice_ptr(d.col_sum, (int)d.N)[gj], s);      // (sliced accumulator: svnet_hip.h)
         }
     }
 }

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void mfma_rows_kernel(RowsArgs a) {
         for (int t = 0; t < NT; ++t) {
             float s = colpart[t] + __shfl_xor(colpart[t], 32, 64);
             const int col = n0 + t * 32 + r;
-            if (h == 0 && col < a.N) atomicAdd(&a.col_sum[col], s);
+            if (h == 0 && col < a.N) atomicAdd(&svnet_slice_ptr(a.col_sum, a.N)[col], s);      // (sliced accumulator: svnet_hip.h)
         }
     }
 }
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void mfma_rows2_kernel(RowsArgs a) {
         for (int j = 0; j < 4; ++j) {
             const float sum = colpart[j] + __shfl_xor(colpart[j], 32, 64);
             const int col = n0 + 128 * wn + 32 * j + r;
-            if (h == 0 && col < a.N) atomicAdd(&a.col_sum[col], sum);
+            if (h == 0 && col < a.N) atomicAdd(&svnet_slice_ptr(a.col_sum, a.N)[col], sum);    // (sliced accumulator: svnet_hip.h)
         }
     }
 }

@@ -150,7 +150,11 @@ __global__ __launch_bounds__(256) void v2s_bwd_kernel(const float* __restrict__ 
         }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < J * C; e += blockDim.x) atomicAdd(&GX[e], gx_lds[e]);
+    // GX: a SLICED accumulator of J * C floats (svnet_hip.h SVNET_SLICED_LEN): 2 048 workgroups adding to the same 3 C addresses were
+    // served one after the other at the memory side - ~45 of this kernel's 92 us at C = 170 (conv5's svfuse); the caller adds the
+    // slices up (svnet_slices_sum_f32)
+    float* gsl = svnet_slice_ptr(GX, J * C);
+    for (int e = threadIdx.x; e < J * C; e += blockDim.x) atomicAdd(&gsl[e], gx_lds[e]);
 }
 
 // Frame projection (the back-projection einsum of sv_pointnet_partseg.py:89): s[m,c*J+j] = sum_i v[m,i,c] * z[m,i,j] with a GIVEN

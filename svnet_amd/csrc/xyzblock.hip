@@ -346,7 +346,8 @@ __global__ __launch_bounds__(256) void xyzblock_bwd_prelude_kernel(
                               gs2_ld, gv2, gv2_ld, gv_sum);
 }
 
-// edge pass: parameter gradients only.  gw layout: [W1 (Os*6NC) | W2 (Ov*NC) | W0 (3NC) | Wz (3NC)], accumulated with atomics.
+// edge pass: parameter gradients only.  gw layout: [W1 (Os*6NC) | W2 (Ov*NC) | W0 (3NC) | Wz (3NC)], accumulated with atomics into the
+// slices of a sliced accumulator (SVNET_SLICED_LEN).
 // Same two phases per point as the forward: the edge's features, v_e and Q_e = v_e^T v_e by the lane that owns the edge, then
 // lanes = output channels over the point's edges (EPI = 2 edges per iteration for <= 32 channels).
 template <int NC, int EPI>
@@ -562,9 +563,12 @@ __global__ __launch_bounds__(256) void xyzblock_bwd_kernel(svnet_xyzblock_bwd_de
         if (lane < NF) atomicAdd(&red[Os * NF + Ov * NC + lane], mine);
     }
     __syncthreads();
+    // (gw: a SLICED accumulator, SVNET_SLICED_LEN(GW): two thousand workgroups adding to the same ~400 addresses are served one after the
+    //  other at the memory side; the caller adds the slices up, svnet_slices_sum_f32)
+    float* gsl = svnet_slice_ptr(d.gw, GW);
     for (int i = threadIdx.x; i < GW; i += blockDim.x) {
         const float v = red[i];
-        if (v != 0.f) atomicAdd(&d.gw[i], v);
+        if (v != 0.f) atomicAdd(&gsl[i], v);
     }
 }
 

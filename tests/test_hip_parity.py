@@ -238,11 +238,12 @@ def test_gemm_rows_mfma_exact_weights(M, K, N, hip_device):
     msg, _ = _planes_row_sliced(keep, hip_device)
     ref = ((A * asc).double() @ Wb.t().double() * csc.double()) * keep.double()
     C = torch.empty(M, N, device=hip_device)
-    cs = torch.zeros(N, device=hip_device)
+    cs = torch.zeros(_ops._sliced_len(N), device=hip_device)             # sliced accumulator (svnet_hip.h): totals by svnet_slices_sum_f32
     _ops.gemm(M, N, K, A=A.to(hip_device), a_rs=K, a_cs=1, a_scale=asc.to(hip_device), B=Wb.to(hip_device), b_rs=1, b_cs=K,
               b_exact=True, C=C, ldc=N, col_scale=csc.to(hip_device), mask=msg, col_sum=cs)
+    _ops.call("svnet_slices_sum_f32", _ops._p(cs), N, _ops._stream())
     assert H.max_rel_err(C.cpu().numpy(), ref.numpy()) < 2e-6
-    assert H.max_rel_err(cs.cpu().numpy(), ref.sum(0).numpy()) < 1e-5
+    assert H.max_rel_err(cs[:N].cpu().numpy(), ref.sum(0).numpy()) < 1e-5
     # NN orientation (dx = g . w_b): B(k,j) = Wb2[k*N + j]
     Wb2 = torch.sign(torch.randn(K, N, generator=g))
     C2 = torch.empty(M, N, device=hip_device)

@@ -17,7 +17,7 @@ Wb = torch.sign(torch.randn(K, N, device=dev, generator=g))
 asc = torch.rand(K, device=dev, generator=g) + 0.5
 mask = torch.randint(-2**62, 2**62, ((M + 63) // 64, N), device=dev, dtype=torch.int64, generator=g)
 C = torch.empty(M, N, device=dev)
-cs = torch.zeros(N, device=dev)
+cs = torch.zeros(_ops._sliced_len(N), device=dev)        # (sliced accumulator)
 
 
 def run():

@@ -30,8 +30,11 @@ v = torch.randn(B, N, 3, 83, device="cuda", requires_grad=True)
 for it in range(3):
     records.clear()
     torch.cuda.synchronize()
-    s5, sv5 = fuse.parts(blk((s, v)))
-    pooled = _ops.GlobalMaxMeanPool.apply(s5, sv5)
+    # (the classifier's own tail, sv_dgcnn_cls.py:69-74: bn1 + LeakyReLU of conv5 inside the pooling pass)
+    bn = blk.bn1
+    y5, v5 = blk.forward_prebn((s, v))
+    sv5 = fuse.v2s(v5)
+    pooled = _ops.GlobalMaxMeanPoolBN.apply(y5, sv5, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, 1, 0.2, bn.num_batches_tracked, bn.eps, 0.1)
     mark = len(records)
     pooled.sum().backward()
     torch.cuda.synchronize()
