@@ -1723,7 +1723,7 @@ class XyzBlock(torch.autograd.Function):
         dW1 = gw[:o].view(Os, NF)
         dW2 = gw[o:o + Ov * NC].view(Ov, NC)
         dW0 = gw[o + Ov * NC:o + Ov * NC + NG].view(3, NC)
-        dWz = gw[o + Ov * NC + NG:].view(3, NC)
+        dWz = gw[o + Ov * NC + NG:o + Ov * NC + 2 * NG].view(3, NC)
         # forward args: x, idx, k, training, W0, Wz, W1, g1, b1, rm1, rv1, W2, g2, b2, rm2, rv2, Wg0, Wg2
         return (None, None, None, None, dW0, dWz, dW1, dg1, db1, None, None, dW2, dg2, db2, None, None, dWg0, dWg2, None, None)
 
