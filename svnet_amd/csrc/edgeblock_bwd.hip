@@ -883,7 +883,22 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
         // ---- pass 4: lanes = elements L of the message row's Vector2Scalar part [dve (3 x Cv) | dz (9)]; centre sums [dv | dz] per point
         {
             const int nout = n3 + 9;
-            for (int L0 = 0; L0 < nout; L0 += 64) {
+            // (Cv = 19 .. 21: the row has 66 .. 72 elements, i.e. a SECOND walk over the wave's eight rows for the last 2 .. 8 of them - all
+            //  dL/dz entries.  They go out in one instruction instead, lane = (row, entry): message part stored, centre part added
+            //  straight to the point's sums; pass 4 was 14 % of a conv4 workgroup's time, profiles/r04_tile_phases.txt)
+            const bool tail_fast = nout > 64 && nout <= 72 && n3 <= 64;
+            if (tail_fast) {
+                const int rr = lane >> 3, tj = lane & 7;
+                const int L = 64 + tj, rw = row0 + rr;
+                const int64_t er = e0 + rw;
+                if (L < nout && er < E) {
+                    const float val = zs[rw * 9 + (L - n3)];
+                    const uint32_t dq_ = small_div((uint32_t)(tp.t0 + rw), tp.kmagic);
+                    st_f32_sbase(d.msg + e0 * R + Cs, (uint32_t)rw * (uint32_t)R * 4u + 4u * (uint32_t)L, val);
+                    ATOMIC_ADD(&d.dzc[(tp.gp0 + dq_) * 9u + (uint32_t)(L - n3)], val);
+                }
+            }
+            for (int L0 = 0; L0 < (tail_fast ? 64 : nout); L0 += 64) {
                 const int L = L0 + lane;
                 const bool on = L < nout;
                 const int Ld = on ? L : 0;
