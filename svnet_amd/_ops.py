@@ -1106,6 +1106,8 @@ class GlobalMaxMeanPoolBN(torch.autograd.Function):
         ctx.save_for_backward(y2, mean, invstd, gamma, beta, arg_a, arg_b)
         if TAP is not None:
             TAP["pools"].append(torch.cat([arg_a, arg_b], dim=1))
+            if "acts" in TAP and act in (1, 2):      # the kink decisions of the BatchNorm + activation the pooling pass evaluates (same expression)
+                TAP["acts"].append((gamma.data_ptr(), ((y2 - mean) * invstd * gamma + beta) > 0))
         ctx.meta = (B, N, Ca, Cb, act, slope, bool(training))
         return out
 
@@ -1440,6 +1442,10 @@ class EdgeBlock(torch.autograd.Function):
         s_view, v_view = _SINK.wrote(s_out, v_out) if slot is not None else (None, None)
         if TAP is not None:      # the pooled slot: BatchNorm + LeakyReLU is increasing (slope coef[o] >= 0: max_k n) or decreasing (min_k n)
             TAP["pools"].append(torch.where(coef[:Os].view(1, Os) >= 0, slot_max, slot_min))
+            # ... and the kink decision of bn1 + LeakyReLU on EVERY edge (sv_layers.py:189-190): the layer's pre-activation is
+            # A1[o] * n + B1[o] with the kept integer n - the expression the apply kernel evaluates at the pooled edge
+            if "acts" in TAP and n16 is not None:
+                TAP["acts"].append((g1.data_ptr(), (coef[:Os].view(1, Os) * n16.float() + coef[Os:2 * Os].view(1, Os)) > 0))
         ctx.save_for_backward(v, idx, zz, ut, w_sign, w_nz, n16, planes, n_max, n_min, slot_max, slot_min, mv, mvn, coef, gate, h,
                               gin, wv, scv, W1c, sc1, W2c, sc2f, Wzc, sczf, g1, g2, Wg0c, Wg2c, wbt)
         ctx.meta = (B, N, k, Cs, Cv, Os, Ov, bool(training), scale1.shape, sc2.shape, scz.shape)

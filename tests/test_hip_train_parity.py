@@ -98,6 +98,7 @@ TRAIN_CASES = [c for c in C.MODEL_CASES if c[0].endswith("_small") and c[0] != "
 # cases held to the north-star tolerance itself (1e-3) on every tensor, whatever the yard-sticks say
 STRICT = ("dgcnn_bin_small", "dgcnn_fp_small", "pseg_bin_small", "dgcnn_bin_b16", "dgcnn_bin_b16b", "dgcnn_bin_b8", "dgcnn_fp_b16",
           "pseg_bin_b32", "pseg_fp_b32", "dgcnn_bin_n1024")
+WIDER_CERTIFICATE = ("ppseg_fp_b16",)          # the one case whose decision certificate allows 30 instead of 20 rms of fp32 noise (see below)
 NO_SENSITIVITY_LEG = ("dgcnn_bin_n1024",)      # STRICT cases never use the float64 sensitivity (a third oracle step: ~1 min at this size)
 YARDSTICK = 3.0         # a tensor may be this many times further from the float64 truth than the fp32 oracle is ...
 SENSITIVITY = 10.0      # ... or this many times what the float64 truth itself moves when its input moves by one part in 1e7
@@ -132,18 +133,21 @@ def _train_step_case(case, hip_device, corrupt=None):
     # 10x its own rms distance from the float64 values there
     # (STRICT cases also replay the kink decisions of the BatchNorm + ReLU / LeakyReLU layers the HIP path runs as such - heads, layer-wise
     #  blocks: a head activation 1e-7 from its kink flipped by a one-ulp change upstream moved pseg_fp_b32's gradients by 2e-3)
-    dmodel = m if tag in STRICT else None
+    # (round 4: EVERY case replays the kink decisions - the fused edge layers' per-edge LeakyReLU and conv5's pooled BatchNorm are tapped
+    #  now as well, svnet_amd._ops.  With them replayed, round 3's loosenings for the ill-conditioned callers were tried without: the
+    #  doubled yard-stick is needed by NO case any more (retired); the wider certificate by ONE decision of ONE case, named below)
+    dmodel = m
     dec64 = decisions_of(tap, model=dmodel)
     dec64.value_record = {"knn": [], "signs": [], "pools": [], "acts": {}}
     lo64, ls64, Pg64 = oracle_step(model, binary, k, x, l, y, dec64, torch.float64)
     dec = decisions_of(tap, model=dmodel)
     dec.truth = dec64.value_record
-    if tag not in STRICT:
-        # The ill-conditioned callers (PointNet family: a 1e-7 input change moves sv_pointnet_partseg's logits by 4e-4) decide their late
-        # max-pools among values that carry amplified rounding noise: the global max over the points of ppseg_fp_b16 has ~20 near-ties
-        # in 65 504 whose gaps spread up to the certificate's threshold (largest margin 0.75 of it with one build of the first-layer
-        # kernel, 1.001 with the next, which only changed a summation order).  The HIP step and the fp32 oracle are two independent
-        # draws of that noise (sqrt 2 of one draw's distance from float64) and the largest of 65 504 is several rms: 30 instead of 20 rms.
+    if tag in WIDER_CERTIFICATE:
+        # ppseg_fp_b16 (sv_pointnet_partseg: a 1e-7 input change moves its logits by 4e-4) decides its global max over the points among
+        # ~20 near-ties in 65 504 values that carry amplified rounding noise, and their gaps spread up to the certificate's threshold:
+        # largest margin 0.75 of it with one build of the first-layer kernel, 1.001 with the next (only a summation order changed),
+        # 1.0007 this round at the default 20 rms with every other loosening off (gpurun_out/r04_t11_retire.log).  The HIP step and the
+        # fp32 oracle are two independent draws of that noise and the largest of 65 504 is several rms: 30 rms for THIS case's certificate.
         dec.noise_factor = 30.0
     lo, ls, Pg = oracle_step(model, binary, k, x, l, y, dec)
     cert = dec.check()
@@ -168,17 +172,16 @@ def _train_step_case(case, hip_device, corrupt=None):
     e_hip, e_orc = case_errors(got, truth), case_errors(ref, truth)
     l_hip, l_orc = H.max_rel_err(logits, lo64.numpy()), H.max_rel_err(lo.numpy(), lo64.numpy())
     strict = tag in STRICT
-    # where the fp32 oracle ITSELF is more than 1e-2 away from its float64 evaluation on some tensor (sv_pointnet_partseg at B = 4: 4e-2
-    # to 1.7e-1) the step is amplified rounding noise end to end; the yard-stick is doubled there - still an order-of-magnitude check
-    # against gross errors, no more than that, and said so in the report
-    yard = YARDSTICK if max(e_orc.values()) < 1e-2 else 2.0 * YARDSTICK
+    # (round 3 doubled the yard-stick where the fp32 oracle itself is > 1e-2 from float64; with the kink decisions of every layer replayed
+    #  no case needs that any more - the worst tensor of the family is 1.9e-2 against a bound of 8.5e-2, gpurun_out/r04_t11_retire.log)
+    yard = YARDSTICK
     tol = {n: GRAD_RTOL if strict else max(GRAD_RTOL, yard * e_orc[n], SENSITIVITY * e_sens[n]) for n in e_hip}
     tol_logits = 1e-3 if strict else max(1e-3, yard * l_orc, SENSITIVITY * l_sens)
     os.makedirs(OUT, exist_ok=True)
     with open(os.path.join(OUT, "train_step_grad_errors_%s.json" % tag), "w") as f:
         json.dump({"logits_err_vs_f64": l_hip, "oracle_fp32_logits_err_vs_f64": l_orc, "loss": [loss, ls, ls64],
                    "worst_grad_err_vs_f64": max(e_hip.values()), "oracle_fp32_worst_grad_err_vs_f64": max(e_orc.values()),
-                   "replayed_decisions": cert, "yardstick_factor": yard,
+                   "replayed_decisions": cert, "yardstick_factor": yard, "certificate_noise_factor": dec.noise_factor,
                    "f64_worst_grad_move_under_1e-7_input_change": max(e_sens.values()), "f64_logits_move_under_1e-7_input_change": l_sens,
                    "grads (hip vs f64, oracle fp32 vs f64, f64 sensitivity, bound, name)":
                        sorted(((e, e_orc[n], e_sens[n], tol[n], n) for n, e in e_hip.items()), reverse=True)[:25]},
