@@ -245,7 +245,9 @@ def one_cpu_thread():
 
 @pytest.mark.parametrize("binary", [False, True], ids=["fp_sgd", "binary_adam"])
 def test_five_optimizer_steps_track_the_oracle(binary, hip_device, one_cpu_thread):
-    """K = 5 optimizer steps (main_cls_dgcnn.py:181-185: zero_grad, forward, cal_loss, backward, step; CosineAnnealingLR per
+    """Pins FIVE SINGLE optimizer steps and the optimizer state across them - not a free-running trajectory: the weights are
+    re-synchronised to the oracle's after every step, and the binary model's Adam runs with eps = 1e-3 instead of 1e-8 (see below).
+    K = 5 optimizer steps (main_cls_dgcnn.py:181-185: zero_grad, forward, cal_loss, backward, step; CosineAnnealingLR per
     step here) of SV-DGCNN (B=16, N=64, k=8) on the HIP path against the same steps of the oracle with torch.optim on the CPU.
     fp model: SGD(momentum 0.9, weight decay 1e-4) as the reference uses; binary model: Adam, exact-STE oracle.
 
