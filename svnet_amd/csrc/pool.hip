@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
 // mean with a long reduced axis: grid (chunks, outer); every chunk writes its partial sums to part[chunk][outer*inner] and
 // pool_mean_finish_kernel adds the chunks in a fixed order (no float atomics: the result is reproducible bit for bit, which
 // matters because these means feed sign() one layer later)
-__global__ __launch_bounds__(256) void pool_mean_split_kernel(const float* __restrict__ x, int64_t R, int64_t inner,
+__global__ __launch_bounds__(1024) void pool_mean_split_kernel(const float* __restrict__ x, int64_t R, int64_t inner,
                                                               int64_t rows_per_chunk, float* __restrict__ part, int64_t total) {
     const int64_t o = blockIdx.y;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
@@ -77,7 +77,7 @@ __device__ __forceinline__ unsigned long long pack_key(float v, int64_t r) {
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
     return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)r);
 }
-__global__ __launch_bounds__(256) void pool_max_split_kernel(const float* __restrict__ x, int64_t R, int64_t inner,
+__global__ __launch_bounds__(1024) void pool_max_split_kernel(const float* __restrict__ x, int64_t R, int64_t inner,
                                                              int64_t rows_per_chunk, unsigned long long* __restrict__ keys) {
     const int64_t o = blockIdx.y;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void pool_max_split_kernel(const float* __rest
 // max AND mean of a long reduced axis in ONE pass over x (the classifiers' global pooling reads its [B,N,C] features once instead
 // of twice): the max part as pool_max_split_kernel (packed keys, atomicMax), the mean part as pool_mean_split_kernel (ordered
 // partial sums).
-__global__ __launch_bounds__(256) void pool_maxmean_split_kernel(const float* __restrict__ x, int64_t R, int64_t inner,
+__global__ __launch_bounds__(1024) void pool_maxmean_split_kernel(const float* __restrict__ x, int64_t R, int64_t inner,
                                                                  int64_t rows_per_chunk, unsigned long long* __restrict__ keys,
                                                                  float* __restrict__ part, int64_t total) {
     const int64_t o = blockIdx.y;
@@ -147,7 +147,7 @@ __device__ __forceinline__ float bnp_act_grad(float z, int act, float slope) {
     if (act == 2) return z > 0.f ? 1.f : 0.f;
     return 1.f;
 }
-__global__ __launch_bounds__(256) void bn_pool_split_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+__global__ __launch_bounds__(1024) void bn_pool_split_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int act, float slope, int64_t R,
                                                             int64_t inner, int64_t rows_per_chunk, unsigned long long* __restrict__ keys,
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void bn_pool_split_kernel(const float* __restr
     }
 }
 // red[0:C] += sum g', red[C:2C] += sum g' xhat with g' = g * act'(z), g = (r == argmax ? gmax : 0) + gmean / R
-__global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float* __restrict__ gmax, const float* __restrict__ gmean, int64_t g_ld,
+__global__ __launch_bounds__(1024) void bn_pool_bwd_reduce_kernel(const float* __restrict__ gmax, const float* __restrict__ gmean, int64_t g_ld,
                                                                  const int32_t* __restrict__ argmax, const float* __restrict__ x,
                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta, int act,
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const float* __
         svnet_slice_add(&sl[inner + i], (float)a1);
     }
 }
-__global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const float* __restrict__ gmax, const float* __restrict__ gmean, int64_t g_ld,
+__global__ __launch_bounds__(1024) void bn_pool_bwd_apply_kernel(const float* __restrict__ gmax, const float* __restrict__ gmean, int64_t g_ld,
                                                                 const int32_t* __restrict__ argmax, const float* __restrict__ x,
                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
 // dx[o,r,i] = add[(o*R + r)*add_ld + i] + gmean[o,i] / R: the backward of a mean over r ADDED to another gradient of the same tensor that
 // arrives as rows of stride add_ld (a column slice of a wider gradient), written once - instead of a broadcast pass (pool_bwd_kernel),
 // and a strided elementwise add of the two.  grid (row chunks, outer).
-__global__ __launch_bounds__(256) void pool_mean_bwd_add_kernel(const float* __restrict__ gmean, const float* __restrict__ add, int64_t add_ld,
+__global__ __launch_bounds__(1024) void pool_mean_bwd_add_kernel(const float* __restrict__ gmean, const float* __restrict__ add, int64_t add_ld,
                                                                 int64_t R, int64_t inner, int64_t rows_per_chunk, float* __restrict__ dx) {
     const int64_t o = blockIdx.y;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
@@ -416,6 +416,13 @@ __global__ void smooth_ce_finish_kernel(const float* __restrict__ partial, int n
 
 }  // namespace
 
+// Threads per workgroup of the (row chunk, outer) kernels whose threads own COLUMNS (`for i = threadIdx.x; i < inner; i += blockDim.x`): one
+// column per thread up to 1024 - with 256 threads a 512-column tensor (conv5's [B, N, 512]) was walked as two column passes one after
+// the other, i.e. with half the loads in flight (bn_pool_fwd 42 us for 67 MB = 1.6 TB/s)
+static unsigned pool_col_block(int64_t inner) {
+    const int64_t b = (inner + 63) / 64 * 64;
+    return (unsigned)(b > 1024 ? 1024 : (b < 64 ? 64 : b));
+}
 static int64_t pool_split_chunks(int64_t outer, int64_t R) {
     int64_t chunks = svnet_cdiv(256 * 8, outer);
     if (chunks > svnet_cdiv(R, 32)) chunks = svnet_cdiv(R, 32);
@@ -445,8 +452,7 @@ extern "C" int svnet_pool_fwd_f32(const float* x, int64_t outer, int64_t R, int6
         chunks = svnet_cdiv(R, rpc);
         if (workspace && workspace_bytes >= (size_t)(chunks * total) * sizeof(float)) {
             float* part = (float*)workspace;
-            const int block = inner >= 256 ? 256 : (inner >= 128 ? 128 : 64);
-            hipLaunchKernelGGL(pool_mean_split_kernel, dim3((unsigned)chunks, (unsigned)outer), dim3(block), 0, st, x, R, inner, rpc, part,
+            hipLaunchKernelGGL(pool_mean_split_kernel, dim3((unsigned)chunks, (unsigned)outer), dim3(pool_col_block(inner)), 0, st, x, R, inner, rpc, part,
                                total);
             SVNET_CHECK_LAUNCH("pool_mean_split_kernel");
             hipLaunchKernelGGL(pool_mean_finish_kernel, dim3(svnet_grid(total, 256)), dim3(256), 0, st, part, chunks, total,
@@ -463,7 +469,7 @@ extern "C" int svnet_pool_fwd_f32(const float* x, int64_t outer, int64_t R, int6
         int64_t chunks = pool_split_chunks(outer, R);
         const int64_t rpc = svnet_cdiv(R, chunks);
         chunks = svnet_cdiv(R, rpc);
-        hipLaunchKernelGGL(pool_max_split_kernel, dim3((unsigned)chunks, (unsigned)outer), dim3(256), 0, st, x, R, inner, rpc, keys);
+        hipLaunchKernelGGL(pool_max_split_kernel, dim3((unsigned)chunks, (unsigned)outer), dim3(pool_col_block(inner)), 0, st, x, R, inner, rpc, keys);
         SVNET_CHECK_LAUNCH("pool_max_split_kernel");
         hipLaunchKernelGGL(pool_max_unpack_kernel, dim3(svnet_grid(total, 256)), dim3(256), 0, st, keys, total, out, argmax, inner, out_ld);
         SVNET_CHECK_LAUNCH("pool_max_unpack_kernel");
@@ -493,7 +499,7 @@ extern "C" int svnet_pool_maxmean_fwd_f32(const float* x, int64_t outer, int64_t
     float* part = (float*)((char*)workspace + key_bytes);
     hipError_t e = hipMemsetAsync(keys, 0, key_bytes, st);
     SVNET_REQUIRE(e == hipSuccess, SVNET_E_LAUNCH, "svnet_pool_maxmean_fwd_f32: memset failed");
-    hipLaunchKernelGGL(pool_maxmean_split_kernel, dim3((unsigned)chunks, (unsigned)outer), dim3(256), 0, st, x, R, inner, rpc, keys, part, total);
+    hipLaunchKernelGGL(pool_maxmean_split_kernel, dim3((unsigned)chunks, (unsigned)outer), dim3(pool_col_block(inner)), 0, st, x, R, inner, rpc, keys, part, total);
     SVNET_CHECK_LAUNCH("pool_maxmean_split_kernel");
     hipLaunchKernelGGL(pool_maxmean_finish_kernel, dim3(svnet_grid(total, 256)), dim3(256), 0, st, keys, part, chunks, total, 1.f / (float)R,
                        out_max, out_mean, argmax, inner, out_ld);
@@ -521,7 +527,7 @@ extern "C" int svnet_bn_pool_fwd_f32(const float* y, const float* mean, const fl
     float* part = (float*)((char*)workspace + key_bytes);
     hipError_t e = hipMemsetAsync(keys, 0, key_bytes, st);
     SVNET_REQUIRE(e == hipSuccess, SVNET_E_LAUNCH, "svnet_bn_pool_fwd_f32: memset failed");
-    hipLaunchKernelGGL(bn_pool_split_kernel, dim3((unsigned)chunks, (unsigned)outer), dim3(256), 0, st, y, mean, invstd, gamma, beta, act,
+    hipLaunchKernelGGL(bn_pool_split_kernel, dim3((unsigned)chunks, (unsigned)outer), dim3(pool_col_block(inner)), 0, st, y, mean, invstd, gamma, beta, act,
                        slope, R, inner, rpc, keys, part, total);
     SVNET_CHECK_LAUNCH("bn_pool_split_kernel");
     hipLaunchKernelGGL(pool_maxmean_finish_kernel, dim3(svnet_grid(total, 256)), dim3(256), 0, st, keys, part, chunks, total, 1.f / (float)R,
@@ -549,12 +555,12 @@ extern "C" int svnet_bn_pool_bwd_f32(const float* gmax, const float* gmean, int6
     };
     int64_t chunks, rpc;
     split(512, chunks, rpc);
-    hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3((unsigned)chunks, (unsigned)outer), dim3(256), 0, st, gmax, gmean, g_ld, argmax, y, mean,
+    hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3((unsigned)chunks, (unsigned)outer), dim3(pool_col_block(inner)), 0, st, gmax, gmean, g_ld, argmax, y, mean,
                        invstd, gamma, beta, act, slope, R, inner, rpc, red);
     SVNET_CHECK_LAUNCH("bn_pool_bwd_reduce_kernel");
     if (dy) {
         split(2048, chunks, rpc);
-        hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3((unsigned)chunks, (unsigned)outer), dim3(256), 0, st, gmax, gmean, g_ld, argmax, y, mean,
+        hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3((unsigned)chunks, (unsigned)outer), dim3(pool_col_block(inner)), 0, st, gmax, gmean, g_ld, argmax, y, mean,
                            invstd, gamma, beta, red, act, slope, train_stats, outer, R, inner, rpc, dy);
         SVNET_CHECK_LAUNCH("bn_pool_bwd_apply_kernel");
     } else {
@@ -595,7 +601,7 @@ extern "C" int svnet_pool_mean_bwd_add_f32(const float* gmean, const float* add,
     if (chunks < 1) chunks = 1;
     const int64_t rpc = svnet_cdiv(R, chunks);
     chunks = svnet_cdiv(R, rpc);
-    hipLaunchKernelGGL(pool_mean_bwd_add_kernel, dim3((unsigned)chunks, (unsigned)outer), dim3(256), 0, (hipStream_t)stream, gmean, add, add_ld,
+    hipLaunchKernelGGL(pool_mean_bwd_add_kernel, dim3((unsigned)chunks, (unsigned)outer), dim3(pool_col_block(inner)), 0, (hipStream_t)stream, gmean, add, add_ld,
                        R, inner, rpc, dx);
     SVNET_CHECK_LAUNCH("pool_mean_bwd_add_kernel");
     return SVNET_OK;
