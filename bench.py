@@ -170,10 +170,10 @@ def cpu_baseline(wl, sample_b=4, timed=3):
 # ----------------------------------------------------------------------------- roofline legs
 
 def measured_traffic(kernel_key):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes of THIS build (profiles/r03_pmc_traffic.json, written by
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes of THIS build (profiles/r04_pmc_traffic.json, written by
     tools/make_traffic_json.py from separate FETCH_SIZE / WRITE_SIZE passes; units and gfx950 corrections as MI355X_MICROARCH.md
     prescribes: 2 x FETCH_SIZE + WRITE_SIZE)."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)
@@ -208,7 +208,8 @@ def dgcnn_cls_legs(args, model, x, train, work, torch, _lib):
         t_rows = _lib.KernelTimer("svnet_gemm_f32", lambda a: (a[0]._obj.M == P_ and a[0]._obj.N == 505 and a[0]._obj.K == 512
                                                                and a[0]._obj.b_exact and not a[0]._obj.a_sign))
         t_tn = _lib.KernelTimer("svnet_edgeblock_wgrad_f32", lambda a: a[9] == 128)            # conv4: Os = 128
-        _lib.TIMERS[:] = [t_tile, t_knn, t_knn2, t_efwd, t_xfwd, t_rows, t_tn]
+        t_i8 = _lib.KernelTimer("svnet_binlinear_i8_fwd_f32", lambda a: a[6] == P_ and a[7] == 505 and a[8] == 512)   # conv5.linear1
+        _lib.TIMERS[:] = [t_tile, t_knn, t_knn2, t_efwd, t_xfwd, t_rows, t_tn, t_i8]
         reps = 3
         for _ in range(reps):
             if args.mode == "train":
@@ -307,6 +308,15 @@ def dgcnn_cls_legs(args, model, x, train, work, torch, _lib):
                                             "frac": round(fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                                             "fp32_equivalent_tflops": round(fl / 3 / (ms * 1e-3) / 1e12, 1),
                                             "what": "dx = (g*scale) . sign(W1) of conv5.linear1: [32768 x 512] x [512 x 505]"}
+        ms = avg_ms(t_i8)
+        if ms:
+            ops = 2.0 * P_ * 505 * 512
+            stages["binlinear_i8_conv5"] = {"bound": "mfma", "ops_int8": ops, "time_us": round(ms * 1e3, 1),
+                                            "achieved": round(ops / (ms * 1e-3) / 1e12, 1), "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
+                                            "frac": round(ops / (ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS, 4),
+                                            "hbm_gbs": round((P_ * 505 * 4 + P_ * 512 * 4 + 3 * P_ * 505 / 8) / (ms * 1e-3) / 1e9, 1),
+                                            "what": "conv5.linear1 forward: ternary [32768 x 505] x [505 x 512] on v_mfma_i32_32x32x32_i8 (exact integer counts); "
+                                                    "the kernel is bound by staging its fp32 operand (hbm_gbs = x read + y written + planes written), not by the matrix pipe"}
         ms = avg_ms(t_tn)
         if ms:
             fl = 2.0 * 320 * 128 * E * 3
