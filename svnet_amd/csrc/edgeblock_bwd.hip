@@ -50,6 +50,12 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// bf16 pieces of dL/dn that phase B of the tile kernel multiplies: 3 = the exact split (fp32-exact products); 2 = hi + mid only (a relative
+// 2^-16 cut of every dL/dn entry: measured this round as an A/B build)
+#ifndef SVNET_DN_PIECES
+#define SVNET_DN_PIECES 3
+#endif
+
 constexpr float VEPS = 1e-6f;
 constexpr int NW = 5;
 constexpr int NCOL = NW * 64;      // 320 feature columns in fused bit order
@@ -665,7 +671,9 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
             uint16_t* o_ = dnb + r * DNB + o4;
             *reinterpret_cast<uint2*>(o_) = make_uint2(h0, h1);
             *reinterpret_cast<uint2*>(o_ + TE * DNB) = make_uint2(m0, m1);
+#if SVNET_DN_PIECES >= 3
             *reinterpret_cast<uint2*>(o_ + 2 * TE * DNB) = make_uint2(l0, l1);
+#endif
         }
     }
     __syncthreads();
@@ -719,14 +727,18 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
                 const int ks = ks0 + kb;
                 if (ks < nks) {
                     const uint16_t* a_ = dnb + r * DNB + ks * 16 + 8 * h;                          // 16-byte aligned: DNB % 8 == 0
-                    const bf16x8 fh = *reinterpret_cast<const bf16x8*>(a_), fm = *reinterpret_cast<const bf16x8*>(a_ + TE * DNB),
-                                 fl = *reinterpret_cast<const bf16x8*>(a_ + 2 * TE * DNB);
+                    const bf16x8 fh = *reinterpret_cast<const bf16x8*>(a_), fm = *reinterpret_cast<const bf16x8*>(a_ + TE * DNB);
+#if SVNET_DN_PIECES >= 3
+                    const bf16x8 fl = *reinterpret_cast<const bf16x8*>(a_ + 2 * TE * DNB);
+#endif
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
                         if (cts[q] >= 0) {  // wave-uniform
                             acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, bfr[kb][q], acc[q], 0, 0, 0);
                             acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fm, bfr[kb][q], acc[q], 0, 0, 0);
+#if SVNET_DN_PIECES >= 3
                             acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, bfr[kb][q], acc[q], 0, 0, 0);
+#endif
                         }
                     }
                 }
@@ -883,22 +895,7 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
         // ---- pass 4: lanes = elements L of the message row's Vector2Scalar part [dve (3 x Cv) | dz (9)]; centre sums [dv | dz] per point
         {
             const int nout = n3 + 9;
-            // (Cv = 19 .. 21: the row has 66 .. 72 elements, i.e. a SECOND walk over the wave's eight rows for the last 2 .. 8 of them - all
-            //  dL/dz entries.  They go out in one instruction instead, lane = (row, entry): message part stored, centre part added
-            //  straight to the point's sums; pass 4 was 14 % of a conv4 workgroup's time, profiles/r04_tile_phases.txt)
-            const bool tail_fast = nout > 64 && nout <= 72 && n3 <= 64;
-            if (tail_fast) {
-                const int rr = lane >> 3, tj = lane & 7;
-                const int L = 64 + tj, rw = row0 + rr;
-                const int64_t er = e0 + rw;
-                if (L < nout && er < E) {
-                    const float val = zs[rw * 9 + (L - n3)];
-                    const uint32_t dq_ = small_div((uint32_t)(tp.t0 + rw), tp.kmagic);
-                    st_f32_sbase(d.msg + e0 * R + Cs, (uint32_t)rw * (uint32_t)R * 4u + 4u * (uint32_t)L, val);
-                    ATOMIC_ADD(&d.dzc[(tp.gp0 + dq_) * 9u + (uint32_t)(L - n3)], val);
-                }
-            }
-            for (int L0 = 0; L0 < (tail_fast ? 64 : nout); L0 += 64) {
+            for (int L0 = 0; L0 < nout; L0 += 64) {
                 const int L = L0 + lane;
                 const bool on = L < nout;
                 const int Ld = on ? L : 0;

@@ -7,7 +7,7 @@ TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o run --output-format csv -- python3 $ROOT/bench.py --no-cpu-baseline --steps 10 > $OUT/${TAG}_bench_traced.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o run --output-format csv -- python3 $ROOT/bench.py --no-cpu-baseline --no-extras --steps 10 > $OUT/${TAG}_bench_traced.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d $OUT/${TAG}_pmc_$c -o run --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline > $OUT/${TAG}_pmc_$c.log 2>&1
 done

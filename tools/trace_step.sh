@@ -6,7 +6,7 @@ TAG=${1:-trace}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o run --output-format csv -- python3 $ROOT/bench.py --no-cpu-baseline --steps 10 "$@" > $OUT/${TAG}_bench_traced.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o run --output-format csv -- python3 $ROOT/bench.py --no-cpu-baseline --no-extras --steps 10 "$@" > $OUT/${TAG}_bench_traced.log 2>&1
 cd $ROOT
 T=$(find $OUT/${TAG}_trace -name "*kernel_trace.csv" | head -1)
 python3 tools/step_trace.py $T > $OUT/${TAG}_step_kernels.txt
