@@ -45,9 +45,9 @@ int svnet_slices_sum_f64(double* buf, int64_t L, void* stream);
 
 /* ABI version = 100 * round-of-change + serial.  It changes whenever an entry point gains / loses an argument or a caller-owned buffer
  * changes its required length (200: sliced accumulators, SVNET_SLICED_LEN; 400: this header; 401: the totals of a sliced accumulator are
- * written by its consumer, svnet_slices_sum_*; 402: GX of svnet_v2s_bwd_*, gw of svnet_xyzblock_bwd_f32 and col_sum of svnet_gemm_f32 are sliced accumulators).  svnet_version() returns the value the
+ * written by its consumer, svnet_slices_sum_*; 402: GX of svnet_v2s_bwd_*, gw of svnet_xyzblock_bwd_f32 and col_sum of svnet_gemm_f32 are sliced accumulators; 403: svnet_binweight_grad_f32 takes sliced inputs).  svnet_version() returns the value the
  * library was BUILT with: a caller compiled against another header must refuse to run (svnet_amd/_lib.py does).                   */
-#define SVNET_ABI_VERSION 402
+#define SVNET_ABI_VERSION 403
 int svnet_version(void);
 const char* svnet_last_error(void);
 
@@ -147,8 +147,11 @@ int svnet_binlinear_i8_fwd_f32(const float* x, int64_t ldx, const float* beta, c
                                uint64_t* x_ste, double* col_sums, void* stream);
 /* Chain rule from GX[o,k] = sum_m g[m,o] x_eff[m,k] to the parameters of a bw layer (App. C2):
  *   dW[o,k] = scale[o]*GX[o,k]*[|W[o,k]|<=1.2],  dscale[o] = sum_k w_b[o,k]*GX[o,k];  accumulate != 0 adds to dW/dscale. */
+/* gx_sliced != 0: GX is a sliced accumulator of O*K floats (SVNET_SLICED_LEN) whose slices are added up on the way in.
+ * sum_buf / sum_len (NULL / 0 to skip): another sliced accumulator whose totals this launch leaves in its first sum_len elements
+ * (the dL/dbeta column sums of the same layer's input-gradient product: saves a svnet_slices_sum_f32 launch).                       */
 int svnet_binweight_grad_f32(const float* GX, const float* W, const float* scale, int64_t O, int64_t K,
-                             float* dW, float* dscale, int accumulate, void* stream);
+                             float* dW, float* dscale, int accumulate, int gx_sliced, float* sum_buf, int64_t sum_len, void* stream);
 
 /* ------------------------------------------------------------------ fused edge block (tier 2)
  * One pass over the edges of a BINARIZED edge layer, never materialising an edge tensor:

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVNET_DIAG_LIB") or os.path.join(_HERE, "libsvnet_hip.so")    # (SVNET_DIAG_LIB: an ablation build, tools/ only)
 _lib = None
-ABI_VERSION = 402       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
+ABI_VERSION = 403       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
 
 c_p = ctypes.c_void_p
 c_i64 = ctypes.c_int64
@@ -137,7 +137,7 @@ SIGNATURES = {
     "svnet_gemm_f32": (c_int, [ctypes.POINTER(GemmDesc), c_p]),
     "svnet_binweight_prepare_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),
     "svnet_binlinear_fwd_f32": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),
-    "svnet_binweight_grad_f32": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_int, c_p]),
+    "svnet_binweight_grad_f32": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_int, c_int, c_p, c_i64, c_p]),
     "svnet_edgeblock_prepare_vec_f32": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p]),
     "svnet_knn_reverse_i32": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_i64, c_p, c_p, c_p]),
     "svnet_edgeblock_msg_stride": (c_i64, [c_i64, c_i64, c_i64]),

@@ -217,13 +217,15 @@ class FpLinear(torch.autograd.Function):
         return dx, dW, db
 
 
-def _binweight_grad(GX, W, sc, O, K, training):
+def _binweight_grad(GX, W, sc, O, K, training, gx_sliced=False, sum_buf=None, sum_len=0):
     """STE chain rule to (W, scale) of a bw layer; eval mode binarizes with a bare sign(): no gradient reaches W
-    (sv_layers.py:44-45)."""
+    (sv_layers.py:44-45).  gx_sliced: GX is a sliced accumulator (its slices are added up by the kernel); sum_buf / sum_len: another
+    sliced accumulator of the same backward whose totals the launch leaves in its first sum_len elements (dL/dbeta)."""
     dev = GX.device
     dsc = torch.empty((O,), dtype=torch.float32, device=dev)
     dW = torch.empty((O, K), dtype=torch.float32, device=dev) if training else torch.zeros((O, K), dtype=torch.float32, device=dev)
-    call("svnet_binweight_grad_f32", _p(GX), _p(W), _p(sc), O, K, _p(dW) if training else None, _p(dsc), 0, _stream())
+    call("svnet_binweight_grad_f32", _p(GX), _p(W), _p(sc), O, K, _p(dW) if training else None, _p(dsc), 0, int(bool(gx_sliced)),
+         _p(sum_buf), int(sum_len), _stream())
     return dW, dsc
 
 
@@ -561,23 +563,34 @@ class BinLinear(torch.autograd.Function):
         dx = dW = dbeta = dsc = dbias = None
         need_x, need_w = ctx.needs_input_grad[0] or ctx.needs_input_grad[2], ctx.needs_input_grad[1] or ctx.needs_input_grad[3]
         beside = _Beside(dev, config.DW_BESIDE and need_x and need_w and ctx.training and M >= config.TWO_STREAM_MIN_ROWS)    # (see BwLinear.backward)
-        if need_w:
+        def wgrad(sum_buf=None, sum_len=0):
             # GX[o,k] = sum_m g[m,o] x_b[m,k], computed as (x_b^T g)[k,o] with the ternary operand on the A side
             GX = _zeros((O, K), torch.float32, dev)           # (accumulate onto zeros from the step's arena: no zero-fill launch of its own)
+            gemm(K, O, M, a_planes=(x_sign, x_nz), B=g2, b_rs=O, b_cs=1, C=GX, ldc=1, c_cs=K, accumulate=True)
+            dW_, dsc_ = _binweight_grad(GX, W, sc, O, K, ctx.training, sum_buf=sum_buf, sum_len=sum_len)
+            return dW_.view(wshape), dsc_.view(sshape)
+
+        if need_w and beside.on:                              # helper-stream form: the weight gradient is issued first, beside the input gradient
             with beside:
-                gemm(K, O, M, a_planes=(x_sign, x_nz), B=g2, b_rs=O, b_cs=1, C=GX, ldc=1, c_cs=K, accumulate=True)
-                dW, dsc = _binweight_grad(GX, W, sc, O, K, ctx.training)
-                dW, dsc = dW.view(wshape), dsc.view(sshape)
+                dW, dsc = wgrad()
+        dbuf = None
         if need_x:
-            dbuf = _zeros((_sliced_len(K),), torch.float32, dev)        # sliced accumulator of the column sums (dL/dbeta)
+            # (otherwise) the input gradient FIRST: its column sums (dL/dbeta, a sliced accumulator) are then totalled by the weight-gradient
+            # epilogue launch below instead of by a launch of their own
+            dbuf = _zeros((_sliced_len(K),), torch.float32, dev)
             if ctx.training:
                 dx = torch.empty((M, K), dtype=torch.float32, device=dev)
                 gemm(M, K, O, A=g2, a_rs=O, a_cs=1, a_scale=sc, B=w_b, b_rs=K, b_cs=1, b_exact=True, C=dx, ldc=K, mask=x_ste, col_sum=dbuf)
-                call("svnet_slices_sum_f32", _p(dbuf), K, _stream())
             else:   # eval: bare sign() has zero gradient (sv_layers.py:38-39)
                 dx = torch.zeros((M, K), dtype=torch.float32, device=dev)
             dx = dx.view(xshape)
             dbeta = dbuf[:K].view(bshape)
+        pending = need_x and ctx.training                     # the slices of dbuf still have to be added up
+        if need_w and not beside.on:
+            dW, dsc = wgrad(dbuf if pending else None, K if pending else 0)
+            pending = False
+        if pending:
+            call("svnet_slices_sum_f32", _p(dbuf), K, _stream())
         beside.join(dW, dsc)
         if has_bias and ctx.needs_input_grad[4]:
             dbias = pool_raw(g2, 1, M, O, 1)[0].view(O) * float(M)
@@ -702,12 +715,12 @@ class V2S(torch.autograd.Function):
         dv = torch.empty_like(v3)
         gxb = _zeros((_sliced_len(J * C),), torch.float32, v3.device)      # sliced accumulator: 2 048 workgroups add to it
         call("svnet_v2s_bwd_f32", _p(v3), _p(w_eff), _p(gs2), _p(gz2), M, C, J, _p(dv), _p(gxb), _stream())
-        call("svnet_slices_sum_f32", _p(gxb), J * C, _stream())
-        GX = gxb[:J * C].view(J, C)
-        dW, dsc = GX, None
         if sc is not None:
-            dW, dsc = _binweight_grad(GX, W, sc, J, C, ctx.training)
+            dW, dsc = _binweight_grad(gxb, W, sc, J, C, ctx.training, gx_sliced=True)      # (adds the slices up on the way in)
             dsc = dsc.view(ctx.sshape)
+        else:
+            call("svnet_slices_sum_f32", _p(gxb), J * C, _stream())
+            dW, dsc = gxb[:J * C].view(J, C), None
         return dv.view(ctx.vshape), dW, dsc, None
 
 
@@ -773,12 +786,12 @@ class V2SCat(torch.autograd.Function):
         dv = torch.empty_like(v3)
         gxb = _zeros((_sliced_len(J * C),), torch.float32, v3.device)
         call("svnet_v2s_bwd_ld_f32", _p(v3), _p(w_eff), _p(g2[:, Cs:]), Cs + C * J, None, M, C, J, _p(dv), _p(gxb), _stream())
-        call("svnet_slices_sum_f32", _p(gxb), J * C, _stream())
-        GX = gxb[:J * C].view(J, C)
-        dW, dsc = GX, None
         if sc is not None:
-            dW, dsc = _binweight_grad(GX, W, sc, J, C, ctx.training)
+            dW, dsc = _binweight_grad(gxb, W, sc, J, C, ctx.training, gx_sliced=True)
             dsc = dsc.view(scshape)
+        else:
+            call("svnet_slices_sum_f32", _p(gxb), J * C, _stream())
+            dW, dsc = gxb[:J * C].view(J, C), None
         return ds, dv.view(vshape), dW, dsc, None, None, None
 
 

@@ -243,17 +243,24 @@ __global__ __launch_bounds__(256) void binlinear_fwd_kernel(const float* __restr
 }
 
 // dW[o,k] (+)= scale[o]*GX[o,k]*[|W|<=1.2] ; dscale[o] (+)= sum_k sign(W[o,k])*GX[o,k].  One wave per output row.
+// gx_sliced: GX is a sliced accumulator of O*K floats (SVNET_SLICED_LEN: Vector2Scalar's weight-gradient sums) whose slices are added up
+// on the way in.  sum_buf / sum_len (optional): another sliced accumulator of this layer's backward (dL/dbeta: the column sums of the
+// input-gradient product) whose totals workgroup 0 leaves in its first sum_len elements - the launch svnet_slices_sum_f32 would have been.
 __global__ __launch_bounds__(256) void binweight_grad_kernel(const float* __restrict__ GX, const float* __restrict__ W,
                                                              const float* __restrict__ scale, int64_t O, int64_t K,
-                                                             float* __restrict__ dW, float* __restrict__ dscale, int accumulate) {
+                                                             float* __restrict__ dW, float* __restrict__ dscale, int accumulate,
+                                                             int gx_sliced, float* __restrict__ sum_buf, int sum_len) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    if (sum_buf && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < sum_len; i += blockDim.x) sum_buf[i] = svnet_slices_total(sum_buf, sum_len, i);
+    const int L = (int)(O * K);
     for (int64_t o = wave; o < O; o += nwaves) {
         const float sc = scale[o];
         float part = 0.f;
         for (int64_t k = lane; k < K; k += 64) {
-            const float w = W[o * K + k], g = GX[o * K + k];
+            const float w = W[o * K + k], g = gx_sliced ? svnet_slices_total(GX, L, (int)(o * K + k)) : GX[o * K + k];
             const float s = (w > 0.f) ? 1.f : ((w < 0.f) ? -1.f : 0.f);
             part += s * g;
             if (dW) {
@@ -356,10 +363,11 @@ extern "C" int svnet_binlinear_fwd_f32(const float* x, int64_t ldx, const float*
 }
 
 extern "C" int svnet_binweight_grad_f32(const float* GX, const float* W, const float* scale, int64_t O, int64_t K,
-                                        float* dW, float* dscale, int accumulate, void* stream) {
-    SVNET_REQUIRE(GX && W && scale && O > 0 && K > 0, SVNET_E_ARG, "svnet_binweight_grad_f32: bad arguments");
+                                        float* dW, float* dscale, int accumulate, int gx_sliced, float* sum_buf, int64_t sum_len, void* stream) {
+    SVNET_REQUIRE(GX && W && scale && O > 0 && K > 0 && O * K < ((int64_t)1 << 30) && (!sum_buf || (sum_len > 0 && sum_len < ((int64_t)1 << 30))),
+                  SVNET_E_ARG, "svnet_binweight_grad_f32: bad arguments");
     hipLaunchKernelGGL(binweight_grad_kernel, dim3(svnet_grid(O * 64, 256)), dim3(256), 0, (hipStream_t)stream, GX, W, scale, O, K,
-                       dW, dscale, accumulate);
+                       dW, dscale, accumulate, gx_sliced, sum_buf, (int)sum_len);
     SVNET_CHECK_LAUNCH("binweight_grad_kernel");
     return SVNET_OK;
 }
