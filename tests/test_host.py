@@ -141,3 +141,29 @@ def test_params_macs_counters_reproduce_the_reference_numbers():
         mf = M.SV_DGCNN_CLS(argparse.Namespace(k=20, binary=False), 40)
     assert abs(pm.get_param(mb) - 3.43) < 0.005 and abs(pm.get_param(mf) - 49.71) < 0.005
     assert len(pm.report()) == 8
+
+
+def test_deferred_weight_gradients_only_when_autograd_merely_adopts_them():
+    """TrainStep hands autograd parameter gradients the side stream has not written yet (config.DEFER_WGRAD): sound only while every
+    parameter belongs to one module, has no hooks, and .grad is None at backward.  The check itself needs no GPU."""
+    from svnet_amd.train import TrainStep
+
+    class Two(torch.nn.Module):
+        def __init__(self, shared):
+            super().__init__()
+            self.a = torch.nn.Linear(4, 4, bias=False)
+            self.b = torch.nn.Linear(4, 4, bias=False)
+            if shared:
+                self.b.weight = self.a.weight
+
+    x, y = torch.zeros(2, 4), torch.zeros(2, dtype=torch.int64)
+    plain = TrainStep(Two(False), (x,), y)
+    assert plain._deferral_is_safe()
+    assert not TrainStep(Two(True), (x,), y)._deferral_is_safe()          # one Parameter used by two modules: its gradients are ADDED
+    hooked = Two(False)
+    hooked.a.weight.register_hook(lambda g: g)
+    assert not TrainStep(hooked, (x,), y)._deferral_is_safe()             # a tensor hook runs on the main stream, on unwritten memory
+    if hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
+        post = Two(False)
+        post.b.weight.register_post_accumulate_grad_hook(lambda p: None)
+        assert not TrainStep(post, (x,), y)._deferral_is_safe()
