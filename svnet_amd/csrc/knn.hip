@@ -17,6 +17,17 @@
 
 #include "common.h"
 
+#ifndef SVNET_KNN_ABL
+#define SVNET_KNN_ABL 0
+#endif
+#ifndef SVNET_KNN_FORCE_MF
+#define SVNET_KNN_FORCE_MF 0
+#endif
+#ifndef SVNET_KNN_MF8
+#define SVNET_KNN_MF8 1
+#endif
+
+
 namespace {
 
 struct Cascade {  // ATen multi_row_sum: 4 levels, level step 16
@@ -50,7 +61,7 @@ template <bool IL4>
 __global__ __launch_bounds__(256) void knn_prep_kernel(const float* __restrict__ x, int64_t B, int64_t N, int64_t C,
                                                        int64_t sb, int64_t sn, int64_t sc, int xx_mode,
                                                        float* __restrict__ xT, float* __restrict__ xx,
-                                                       const float* __restrict__ x2, int64_t split) {
+                                                       const float* __restrict__ x2, int64_t split, int64_t Cpad) {
     constexpr int il4 = IL4 ? 1 : 0;
     const int64_t total = B * N;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
@@ -70,8 +81,8 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float* __restrict__
             __device__ __forceinline__ void put(int64_t c, float v) const {
                 if (IL4) base[((c >> 2) * N + n) * 4 + (c & 3)] = v; else base[c * N + n] = v;
             }
-        } dst = {xT + b * (il4 ? C4 : C) * N, N, n};
-        if (il4) for (int64_t c = C; c < C4; ++c) dst.put(c, 0.f);                   // padding channels: zeros (never NaN bit patterns)
+        } dst = {xT + b * (il4 ? C4 : Cpad) * N, N, n};                              // (channel-major: Cpad >= C rows per cloud)
+        for (int64_t c = C; c < (il4 ? C4 : Cpad); ++c) dst.put(c, 0.f);             // padding channels: zeros (never NaN bit patterns)
         float result;
         if (xx_mode == 0) {
             // outer-dim reduction: columns n < 32*floor(N/32) use one cascade, the rest ATen's row_sum (ilp 4)
@@ -270,6 +281,98 @@ __device__ __forceinline__ void sort_step_pair(uint32_t& hi, uint32_t& lo, int l
 __device__ __forceinline__ void wave_sort_keys(uint32_t& key, int lane) { SVNET_SORT_NETWORK(sort_step_key, key, lane); }
 __device__ __forceinline__ void wave_sort_pairs(uint32_t& hi, uint32_t& lo, int lane) { SVNET_SORT_NETWORK(sort_step_pair, hi, lo, lane); }
 
+// Selection: a wave holds the inner products of Q queries with ALL the cloud's candidates (candidate j = lane + 64 t in acc[q][t]),
+// turns them into pd(i, j) and writes the k first-ranked ids of each query.  cand_v / cand_j: this wave's CAP slots of LDS.
+template <int T, int Q, int CAP>
+__device__ __forceinline__ void knn_select(float (&acc)[Q][T], const float* __restrict__ xxb, int N, int k, int lane, float* cand_v, int* cand_j,
+                                           const int (&qid)[Q], int64_t* __restrict__ idx_cloud) {
+    float xxj[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int j = lane + 64 * t;
+        xxj[t] = (j < N) ? xxb[j] : 0.f;
+    }
+
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        if (qid[q] >= N) continue;  // wave-uniform
+        const float xxi = xxb[qid[q]];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int j = lane + 64 * t;
+            const float inner = -2.0f * acc[q][t];                 // exact
+            const float t1 = __fsub_rn(-xxj[t], inner);            // fl(-xx[j] - inner)
+            const float pd = __fsub_rn(t1, xxi);                   // fl(.. - xx[i])
+            acc[q][t] = (j < N) ? pd : -INFINITY;
+        }
+        // ---- top-k selection.  Threshold pass: the k-th largest of the 64 lane maxima is a lower bound of the k-th
+        // largest distance, so every winner is >= it; those few candidates (typically < 2k) are compacted into LDS
+        // with ballot prefix sums and sorted across the wave.  If more than 64 qualify (heavy ties) fall back to k
+        // rounds of wave-wide arg-max.
+        int mine = 0;
+        float lm = acc[q][0];
+#pragma unroll
+        for (int t = 1; t < T; ++t) lm = fmaxf(lm, acc[q][t]);
+        {
+            uint32_t key = ord_key(lm);
+            wave_sort_keys(key, lane);
+            lm = ord_val((uint32_t)__shfl((int)key, k - 1, 64));   // threshold (wave-uniform): the k-th largest lane maximum
+        }
+        int count = 0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const bool in = acc[q][t] >= lm;
+            const uint64_t m = __ballot(in);
+            const int pos = count + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (in && pos < CAP) {
+                cand_v[pos] = acc[q][t];
+                cand_j[pos] = lane + 64 * t;
+            }
+            count += __popcll(m);
+        }
+        if (count <= CAP) {  // wave-uniform
+            const float cv = (lane < count) ? cand_v[lane] : -INFINITY;
+            const int cj = (lane < count) ? cand_j[lane] : 0x7fffffff;
+            uint32_t hi = ord_key(cv), lo = ~(uint32_t)cj;
+            wave_sort_pairs(hi, lo, lane);
+            // More than 64 qualified (k close to 64: the k-th largest of 64 lane maxima is a weak bound - at N = 2048, k = 40 the
+            // expected count is 62): every further chunk of 64 is sorted the same way and merged in - max(A[i], B[63 - i]) of two
+            // descending runs holds the 64 first-ranked of their union as a bitonic sequence, which the last stage of the network sorts.
+            for (int c0 = 64; c0 < count; c0 += 64) {
+                const float cv2 = (c0 + lane < count) ? cand_v[c0 + lane] : -INFINITY;
+                const int cj2 = (c0 + lane < count) ? cand_j[c0 + lane] : 0x7fffffff;
+                uint32_t hi2 = ord_key(cv2), lo2 = ~(uint32_t)cj2;
+                wave_sort_pairs(hi2, lo2, lane);
+                const uint32_t rh = (uint32_t)__shfl((int)hi2, 63 - lane, 64), rl = (uint32_t)__shfl((int)lo2, 63 - lane, 64);
+                const bool take = ((((uint64_t)rh << 32) | rl) > (((uint64_t)hi << 32) | lo));
+                hi = take ? rh : hi;
+                lo = take ? rl : lo;
+                sort_step_pair<64, 32>(hi, lo, lane); sort_step_pair<64, 16>(hi, lo, lane); sort_step_pair<64, 8>(hi, lo, lane);
+                sort_step_pair<64, 4>(hi, lo, lane); sort_step_pair<64, 2>(hi, lo, lane); sort_step_pair<64, 1>(hi, lo, lane);
+            }
+            mine = (int)~lo;
+        } else {
+            for (int s = 0; s < k; ++s) {
+                float bv = acc[q][0];
+                int bt = 0;
+#pragma unroll
+                for (int t = 1; t < T; ++t) {
+                    const bool g = acc[q][t] > bv;  // strict: first (lowest j) wins inside a lane
+                    bv = g ? acc[q][t] : bv;
+                    bt = g ? t : bt;
+                }
+                int bj = lane + 64 * bt;
+                wave_argmax(bv, bj);
+                if (lane == s) mine = bj;
+#pragma unroll
+                for (int t = 0; t < T; ++t) acc[q][t] = (bj == lane + 64 * t) ? -INFINITY : acc[q][t];
+            }
+        }
+        // (NaN distances compare false everywhere and can leave slots unfilled: never hand an out-of-range id to the gathers)
+        if (lane < k) idx_cloud[(size_t)qid[q] * k + lane] = ((unsigned)mine < (unsigned)N) ? mine : qid[q];
+    }
+}
+
 // T candidates per lane (64*T >= N), Q query rows per wave, 4 waves per workgroup.
 // STAGE: the four waves of a workgroup share the candidate rows through LDS (CC channels at a time, N % 4 == 0): every wave
 // needs the whole [C, N] table of its cloud, so without sharing the L2 -> CU traffic is 4x what the arithmetic can hide.
@@ -340,7 +443,7 @@ __global__ __launch_bounds__(64 * WPB, (T == 32 && SPLIT && !MF) ? 2 : 1) void k
                                                    : make_float4(0.f, 0.f, 0.f, 0.f);               \
         }                                                                                           \
     } while (0)
-        if (SPLIT && DIRECT) {
+        if constexpr (SPLIT && DIRECT) {
             constexpr int TS = T / WPB > 0 ? T / WPB : 1, QB = WPB * Q;
             const int qb0 = bx * QB;
             const int C4 = (C + 3) & ~3;
@@ -421,14 +524,19 @@ __global__ __launch_bounds__(64 * WPB, (T == 32 && SPLIT && !MF) ? 2 : 1) void k
 #pragma unroll
                     for (int t = 0; t < T; ++t) acc[q][t] = mine_[q][t];
             } else {
-            int joff[TS];
+            // lane l carries the candidates 64*TS*wave + 256*(t/4) + 4*l + (t%4) of its wave's slice: four consecutive floats of a channel
+            // per load instruction (the L2 -> CU path was the loop's limit with one float per lane and load: 7.8 TB/s at every width),
+            // pairs (t, t+1) in adjacent registers as the packed FMAs want them.  The hand-over below restores the order lane + 64*t.
+            static_assert(TS % 4 == 0, "four candidates per lane and load");
+            constexpr int TV = TS / 4;
+            int joff[TV];
     #pragma unroll
-                for (int t = 0; t < TS; ++t) joff[t] = min(64 * TS * wave + 64 * t + lane, N - 1);
-                float cn[4][TS];
+                for (int v = 0; v < TV; ++v) joff[v] = min(64 * TS * wave + 256 * v + 4 * lane, N - 4);     // (N % 16 == 0)
+                float4 cn[4][TV];
     #define SVNET_KNN_LOADC(SLOT, CH)                                                                   \
         do {                                                                                            \
-            const float* r_ = xb + (size_t)min((CH), C - 1) * N;                                        \
-            _Pragma("unroll") for (int t = 0; t < TS; ++t) cn[SLOT][t] = r_[joff[t]];                   \
+            const float* r_ = xb + (size_t)(SVNET_KNN_ABL == 3 ? 0 : min((CH), C - 1)) * N;               \
+            _Pragma("unroll") for (int v = 0; v < TV; ++v) cn[SLOT][v] = *reinterpret_cast<const float4*>(r_ + joff[v]);   \
         } while (0)
                 SVNET_KNN_LOADC(0, 0); SVNET_KNN_LOADC(1, 1); SVNET_KNN_LOADC(2, 2);
                 __syncthreads();
@@ -444,11 +552,14 @@ __global__ __launch_bounds__(64 * WPB, (T == 32 && SPLIT && !MF) ? 2 : 1) void k
                             const float4 q4 = *reinterpret_cast<const float4*>(rows + c * QB + 4 * i);   // broadcast read (zeros past C)
                             qv[4 * i] = q4.x; qv[4 * i + 1] = q4.y; qv[4 * i + 2] = q4.z; qv[4 * i + 3] = q4.w;
                         }
+                        float cv[TS];
+    #pragma unroll
+                        for (int v = 0; v < TV; ++v) { cv[4 * v] = cn[u][v].x; cv[4 * v + 1] = cn[u][v].y; cv[4 * v + 2] = cn[u][v].z; cv[4 * v + 3] = cn[u][v].w; }
     #pragma unroll
                         for (int q = 0; q < QB; ++q)
     #pragma unroll
                             for (int t = 0; t < TS; ++t)
-                                accs[(q * TS + t) / T][(q * TS + t) % T] = __builtin_fmaf(qv[q], cn[u][t], accs[(q * TS + t) / T][(q * TS + t) % T]);
+                                accs[(q * TS + t) / T][(q * TS + t) % T] = __builtin_fmaf(qv[q], cv[t], accs[(q * TS + t) / T][(q * TS + t) % T]);
                     }
                 }
 #undef SVNET_KNN_LOADC
@@ -510,7 +621,8 @@ __global__ __launch_bounds__(64 * WPB, (T == 32 && SPLIT && !MF) ? 2 : 1) void k
                 for (int q = 0; q < PQ; ++q) {
                     const int qq = pass * PQ + q;
 #pragma unroll
-                    for (int t = 0; t < TS; ++t) rows[q * NP + 64 * TS * wave + 64 * t + lane] = accs[(qq * TS + t) / T][(qq * TS + t) % T];
+                    for (int t = 0; t < TS; ++t)
+                        rows[q * NP + 64 * TS * wave + (DIRECT ? 256 * (t >> 2) + 4 * lane + (t & 3) : 64 * t + lane)] = accs[(qq * TS + t) / T][(qq * TS + t) % T];
                 }
                 __syncthreads();
                 if ((wave * Q) / PQ == pass) {                       // the waves whose Q queries lie in this pass
@@ -557,95 +669,174 @@ __global__ __launch_bounds__(64 * WPB, (T == 32 && SPLIT && !MF) ? 2 : 1) void k
     }
     }
 
-    float xxj[T];
+#if SVNET_KNN_ABL == 1 || SVNET_KNN_ABL == 3   // (3: every channel's candidates from channel 0's row - the loop without its L2 traffic)
+  // diagnostic build (tools/knn_lab.py): the distance phase alone - no selection, the sums keep the accumulators alive
+    {
+        float sm = 0.f;
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const int j = lane + 64 * t;
-        xxj[t] = (j < N) ? xxb[j] : 0.f;
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int t = 0; t < T; ++t) sm += acc[q][t];
+        if (lane < k) idx_out[((size_t)b * N + q0) * k + lane] = (int64_t)(sm > 0.f);
+        return;
     }
+#endif
+    int qid[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) qid[q] = q0 + q;
+    knn_select<T, Q, CAP>(acc, xxb, N, k, lane, cand_v + wave * CAP, cand_j + wave * CAP, qid, idx_out + (size_t)b * N * k);
+}
 
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        if (q0 + q >= N) break;  // wave-uniform
-        const float xxi = xxb[q0 + q];
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int j = lane + 64 * t;
-            const float inner = -2.0f * acc[q][t];                 // exact
-            const float t1 = __fsub_rn(-xxj[t], inner);            // fl(-xx[j] - inner)
-            const float pd = __fsub_rn(t1, xxi);                   // fl(.. - xx[i])
-            acc[q][t] = (j < N) ? pd : -INFINITY;
-        }
-        // ---- top-k selection.  Threshold pass: the k-th largest of the 64 lane maxima is a lower bound of the k-th
-        // largest distance, so every winner is >= it; those few candidates (typically < 2k) are compacted into LDS
-        // with ballot prefix sums and sorted across the wave.  If more than 64 qualify (heavy ties) fall back to k
-        // rounds of wave-wide arg-max.
-        int mine = 0;
-        float lm = acc[q][0];
-#pragma unroll
-        for (int t = 1; t < T; ++t) lm = fmaxf(lm, acc[q][t]);
-        {
-            uint32_t key = ord_key(lm);
-            wave_sort_keys(key, lane);
-            lm = ord_val((uint32_t)__shfl((int)key, k - 1, 64));   // threshold (wave-uniform): the k-th largest lane maximum
-        }
-        int count = 0;
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const bool in = acc[q][t] >= lm;
-            const uint64_t m = __ballot(in);
-            const int pos = count + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (in && pos < CAP) {
-                cand_v[wave * CAP + pos] = acc[q][t];
-                cand_j[wave * CAP + pos] = lane + 64 * t;
-            }
-            count += __popcll(m);
-        }
-        if (count <= CAP) {  // wave-uniform
-            const float cv = (lane < count) ? cand_v[wave * CAP + lane] : -INFINITY;
-            const int cj = (lane < count) ? cand_j[wave * CAP + lane] : 0x7fffffff;
-            uint32_t hi = ord_key(cv), lo = ~(uint32_t)cj;
-            wave_sort_pairs(hi, lo, lane);
-            // More than 64 qualified (k close to 64: the k-th largest of 64 lane maxima is a weak bound - at N = 2048, k = 40 the
-            // expected count is 62): every further chunk of 64 is sorted the same way and merged in - max(A[i], B[63 - i]) of two
-            // descending runs holds the 64 first-ranked of their union as a bitonic sequence, which the last stage of the network sorts.
-            for (int c0 = 64; c0 < count; c0 += 64) {
-                const float cv2 = (c0 + lane < count) ? cand_v[wave * CAP + c0 + lane] : -INFINITY;
-                const int cj2 = (c0 + lane < count) ? cand_j[wave * CAP + c0 + lane] : 0x7fffffff;
-                uint32_t hi2 = ord_key(cv2), lo2 = ~(uint32_t)cj2;
-                wave_sort_pairs(hi2, lo2, lane);
-                const uint32_t rh = (uint32_t)__shfl((int)hi2, 63 - lane, 64), rl = (uint32_t)__shfl((int)lo2, 63 - lane, 64);
-                const bool take = ((((uint64_t)rh << 32) | rl) > (((uint64_t)hi << 32) | lo));
-                hi = take ? rh : hi;
-                lo = take ? rl : lo;
-                sort_step_pair<64, 32>(hi, lo, lane); sort_step_pair<64, 16>(hi, lo, lane); sort_step_pair<64, 8>(hi, lo, lane);
-                sort_step_pair<64, 4>(hi, lo, lane); sort_step_pair<64, 2>(hi, lo, lane); sort_step_pair<64, 1>(hi, lo, lane);
-            }
-            mine = (int)~lo;
-        } else {
-            for (int s = 0; s < k; ++s) {
-                float bv = acc[q][0];
-                int bt = 0;
-#pragma unroll
-                for (int t = 1; t < T; ++t) {
-                    const bool g = acc[q][t] > bv;  // strict: first (lowest j) wins inside a lane
-                    bv = g ? acc[q][t] : bv;
-                    bt = g ? t : bt;
-                }
-                int bj = lane + 64 * bt;
-                wave_argmax(bv, bj);
-                if (lane == s) mine = bj;
-#pragma unroll
-                for (int t = 0; t < T; ++t) acc[q][t] = (bj == lane + 64 * t) ? -INFINITY : acc[q][t];
-            }
-        }
-        // (NaN distances compare false everywhere and can leave slots unfilled: never hand an out-of-range id to the gathers)
-        if (lane < k) idx_out[((size_t)b * N + (q0 + q)) * k + lane] = ((unsigned)mine < (unsigned)N) ? mine : (q0 + q);
+// ---- Matrix-core form for 512 < N <= 1024 (N % 16 == 0): 32 queries per 8-wave workgroup.
+// Where the time of the vector form went (tools/knn_lab.py, B = 32, N = 1024, k = 20): its distance loop runs at 70 % of what the
+// packed-FMA pipe sustains (119 TFLOP/s at the clock the chip holds under this load, not the 157 of the data sheet) whether its
+// candidates come from L2 or from L1, so it cannot get shorter on the vector ALUs - and the selection needs those same ALUs.  Round 3's
+// matrix-core form was slower for a different reason: one query tile per wave means one operand register from L2 per MFMA (4 TB/s).
+// Here the table goes through LDS in chunks of KC channels (coalesced 16-byte loads, each byte fetched once per 32 queries), a wave
+// multiplies 2 query tiles x NTL candidate tiles (10 operand reads from LDS per 16 MFMAs), and the finished inner products are handed
+// over through the same LDS to the layout the selection works on.  v_mfma_f32_16x16x4_f32 adds its four products in channel order with
+// one rounding each: the fmaf chain of the contract, bit for bit.  Two workgroups per CU: one's MFMA phase beside the other's selection.
+template <int T>
+__global__ __launch_bounds__(512, 4) void knn_mf8_kernel(const float* __restrict__ xT, const float* __restrict__ xx, int N, int C, int k,
+                                                         int64_t* __restrict__ idx_out, int xcd_blocks_per_cloud) {
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    constexpr int NP = 64 * T;                 // candidate columns of a staged row (>= N)
+    constexpr int LDS_S = NP + 16;             // staged row stride: the four channel rows of a k-step start 16 banks apart
+    constexpr int LDS_H = NP + 4;              // hand-over row stride: the four query rows a tile's lanes write lie 16 banks apart
+    constexpr int KC = 4, NB = 4;              // channels per staged k-step of the 16x16x4 product, buffers in the ring
+    constexpr int WPB = 8, QB = 32, Q = 4;
+    constexpr int CW = NP / WPB;               // candidates per wave in the distance phase
+    constexpr int NTL = CW / 16;               // 16-candidate tiles per wave
+    constexpr int CAP = T >= 32 ? 256 : 128;
+    static_assert(16 * LDS_H <= NB * KC * LDS_S, "the hand-over fits in the staging buffers");
+    __shared__ float cand_v[WPB * CAP];
+    __shared__ int cand_j[WPB * CAP];
+    extern __shared__ __attribute__((aligned(16))) float rows[];          // [NB][KC][LDS_S]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int bx = blockIdx.x, b = blockIdx.y;
+    if (gridDim.y == 1 && xcd_blocks_per_cloud > 0) {                     // XCD-aware cloud order, as in knn_main_kernel
+        const int w = blockIdx.x, per = xcd_blocks_per_cloud;
+        b = (w / (per * 8)) * 8 + (w & 7);
+        bx = (w >> 3) % per;
     }
+    const int qb0 = bx * QB;
+    const float* __restrict__ xxb = xx + (size_t)b * N;
+    const int kl = lane >> 4, jl = lane & 15;
+
+    // Staging: LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes = 256 consecutive candidates of one channel row, no registers) into
+    // a ring of NB buffers of one k-step (4 channel rows) each.  The table's clouds are C8 = 8 ceil(C / 8) rows apart and the rows past C
+    // hold zeros, so every k-step is whole.  At the top of step s: k-steps <= s + 1 have landed and been seen by every wave (the wait and
+    // barrier that ended step s - 1), k-step s + 2 is in flight, k-step s's operands are in registers.  Step s then requests k-step s + 3
+    // (into the buffer whose operands were read during step s - 2), reads the operands of s + 1 and issues the products of s - nothing
+    // in it waits for a round trip.  Every wave issues DMA_PER instructions per k-step whatever N is (columns past N: a clamped source),
+    // so that the counted wait means the same in all of them.
+    const int C8 = (C + 7) / 8 * 8;
+    const float* __restrict__ xb8 = xT + (size_t)b * C8 * N;
+    typedef __attribute__((address_space(3))) float lds_f32;
+    typedef const __attribute__((address_space(1))) float glb_f32;
+    constexpr int DMA_PER = KC * (NP / 256) / WPB;                       // 2 at N <= 1024
+    static_assert(DMA_PER * WPB == KC * (NP / 256) && DMA_PER == 2, "the counted waits below assume two DMA instructions per wave and k-step");
+    const int nks = (C + 3) >> 2;
+#define SVNET_KNN_DMA4(S)                                                                           \
+    do {                                                                                            \
+        const int s_ = min((S), nks - 1);                                                           \
+        float* buf_ = rows + ((S) & (NB - 1)) * (KC * LDS_S);                                       \
+        _Pragma("unroll") for (int u = 0; u < DMA_PER; ++u) {                                       \
+            const int e_ = wave * DMA_PER + u, rw_ = e_ / (NP / 256), i_ = e_ - rw_ * (NP / 256);  \
+            __builtin_amdgcn_global_load_lds((glb_f32*)(xb8 + (size_t)(4 * s_ + rw_) * N + min(256 * i_, N - 256) + 4 * lane),     \
+                                             (lds_f32*)(buf_ + rw_ * LDS_S + 256 * i_), 16, 0, 0);                                  \
+        }                                                                                           \
+    } while (0)
+    // lane l = (kl = l >> 4, jl = l & 15): A[i = jl][kl] = x[4 s + kl][qb0 + 16 a + jl], B[kl][j = jl] = x[4 s + kl][candidate]
+#define SVNET_KNN_OPERANDS(S, AV, BV)                                                               \
+    do {                                                                                            \
+        const float* rk_ = rows + ((S) & (NB - 1)) * (KC * LDS_S) + kl * LDS_S + jl;                \
+        AV[0] = rk_[qb0]; AV[1] = rk_[qb0 + 16];                                                    \
+        _Pragma("unroll") for (int tt = 0; tt < NTL; ++tt) BV[tt] = rk_[CW * wave + 16 * tt];       \
+    } while (0)
+#define SVNET_KNN_PRODUCTS_HALF(AV, BV, H)                                                          \
+    do {                                                                                            \
+        _Pragma("unroll") for (int tt = (H) * (NTL / 2); tt < ((H) + 1) * (NTL / 2); ++tt) {        \
+            dacc[0][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[0], BV[tt], dacc[0][tt], 0, 0, 0); \
+            dacc[1][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[1], BV[tt], dacc[1][tt], 0, 0, 0); \
+        }                                                                                           \
+    } while (0)
+    // end of a step: all but the newest k-step's DMA have landed (this wave's share; the barrier makes it everyone's); the wave's own LDS
+    // reads are waited for by the compiler where their values are first used (the operand copies behind the barrier)
+#define SVNET_KNN_STEP_END()                                                                        \
+    do {                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                            \
+        __builtin_amdgcn_s_barrier();                                                               \
+        asm volatile("" ::: "memory");                                                              \
+    } while (0)
+
+    f32x4 dacc[2][NTL];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int tt = 0; tt < NTL; ++tt) dacc[a][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float av[2], bv[NTL], avn[2], bvn[NTL];
+    SVNET_KNN_DMA4(0); SVNET_KNN_DMA4(1); SVNET_KNN_DMA4(2);
+    SVNET_KNN_STEP_END();                                                // k-steps 0 and 1 have landed
+    SVNET_KNN_OPERANDS(0, av, bv);
+    for (int s = 0; s < nks; ++s) {
+        SVNET_KNN_DMA4(s + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        SVNET_KNN_PRODUCTS_HALF(av, bv, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        SVNET_KNN_OPERANDS(s + 1, avn, bvn);                             // (past the last k-step: a landed buffer, values unused)
+        __builtin_amdgcn_sched_barrier(0);
+        SVNET_KNN_PRODUCTS_HALF(av, bv, 1);
+        SVNET_KNN_STEP_END();
+        av[0] = avn[0]; av[1] = avn[1];
+#pragma unroll
+        for (int tt = 0; tt < NTL; ++tt) bv[tt] = bvn[tt];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the ring's last requests, before the hand-over reuses the buffers
+    __syncthreads();
+#undef SVNET_KNN_DMA4
+#undef SVNET_KNN_OPERANDS
+#undef SVNET_KNN_PRODUCTS_HALF
+#undef SVNET_KNN_STEP_END
+
+    // hand-over, 16 queries per pass: D register g of tile (a, tt) in lane l = query 16 a + 4 kl + g, candidate CW wave + 16 tt + jl;
+    // every wave then takes two queries of the pass - after both passes it holds 4 queries x all candidates, candidate lane + 64 t
+    float acc[Q][T];
+    int qid[Q];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass) __syncthreads();                                       // the first pass has been read
+#pragma unroll
+        for (int tt = 0; tt < NTL; ++tt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) rows[(4 * kl + g) * LDS_H + CW * wave + 16 * tt + jl] = dacc[pass][tt][g];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            qid[2 * pass + r] = qb0 + 16 * pass + 2 * wave + r;
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[2 * pass + r][t] = rows[(2 * wave + r) * LDS_H + 64 * t + lane];
+        }
+    }
+#if SVNET_KNN_ABL >= 1   // diagnostic builds: no selection
+    {
+        float sm = 0.f;
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int t = 0; t < T; ++t) sm += acc[q][t];
+        if (lane < k) idx_out[((size_t)b * N + qid[0]) * k + lane] = (int64_t)(sm > 0.f);
+        return;
+    }
+#endif
+    knn_select<T, Q, CAP>(acc, xxb, N, k, lane, cand_v + wave * CAP, cand_j + wave * CAP, qid, idx_out + (size_t)b * N * k);
 }
 
 template <int T, int Q>
-void launch_main(const float* xT, const float* xx, int64_t B, int N, int C, int k, int64_t* idx, hipStream_t st) {
+void launch_main(const float* xT, const float* xx, int64_t B, int N, int C, int k, int64_t* idx, hipStream_t st, bool mf8 = false) {
     dim3 grid((unsigned)svnet_cdiv(N, 4 * Q), (unsigned)B);
     int per = 0;
     if ((B & 7) == 0) { per = (int)grid.x; grid = dim3((unsigned)(grid.x * B), 1u); }   // XCD-aware cloud order (see the kernel)
@@ -655,7 +846,19 @@ void launch_main(const float* xT, const float* xx, int64_t B, int N, int C, int 
     // SVNET_KNN_MFMA=1: the distance loop on the f32 matrix cores.  Measured (round 3, B=32 N=1024, the three feature-space graphs of
     // the bench): bit-identical neighbour lists on all 33 parity cases, and 183 us per call against 111 us for the vector form -
     // so the vector form stays the default.
-    static const bool valu = getenv("SVNET_KNN_MFMA") == nullptr;
+    static const bool valu = getenv("SVNET_KNN_MFMA") == nullptr && !SVNET_KNN_FORCE_MF;
+    if constexpr (T == 16 && Q == 4) {
+        if (mf8) {                            // 32 queries per workgroup on the f32 matrix cores (channel-major table)
+            constexpr size_t lds = (size_t)2 * 8 * (64 * T + 16) * sizeof(float);
+            static const int once = hipFuncSetAttribute((const void*)knn_mf8_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)once;
+            dim3 g8((unsigned)svnet_cdiv(N, 32), (unsigned)B);
+            int per8 = 0;
+            if ((B & 7) == 0) { per8 = (int)g8.x; g8 = dim3((unsigned)(g8.x * B), 1u); }
+            hipLaunchKernelGGL((knn_mf8_kernel<T>), g8, dim3(512), lds, st, xT, xx, N, C, k, idx, per8);
+            return;
+        }
+    }
     if constexpr ((T == 16 || T == 32) && Q == 4) {
         if ((N & 15) == 0 && !valu) {                                   // inner products on the f32 matrix cores
             hipLaunchKernelGGL((knn_main_kernel<T, Q, (T >= 4 && T <= 16), true, 4, true, true>), grid, dim3(256), (size_t)32768, st, xT, xx, N, C, k,
@@ -678,7 +881,7 @@ void launch_main(const float* xT, const float* xx, int64_t B, int N, int C, int 
 
 extern "C" size_t svnet_knn_workspace_bytes(int64_t B, int64_t N, int64_t C) {
     if (B < 0 || N < 0 || C < 0) return 0;
-    return (size_t)(B * N * ((C + 3) / 4 * 4) + B * N) * sizeof(float) + 256;     // (channels padded to a multiple of 4: the interleaved table)
+    return (size_t)(B * N * ((C + 7) / 8 * 8) + B * N) * sizeof(float) + 256;     // (channels padded to a multiple of 8: whole chunks of the matrix-core form)
 }
 
 static int knn_impl(const float* x, const float* x2, int64_t split, int64_t B, int64_t N, int64_t C, int64_t sb, int64_t sn, int64_t sc,
@@ -709,23 +912,26 @@ static int knn_impl(const float* x, const float* x2, int64_t split, int64_t B, i
     if (B == 0) return SVNET_OK;
     hipStream_t st = (hipStream_t)stream;
     float* xT = (float*)workspace;
-    float* xx = xT + B * N * ((C + 3) / 4 * 4);
+    const int64_t C8 = (C + 7) / 8 * 8;
+    float* xx = xT + B * N * C8;
     // the matrix-core form of the main kernel (512 < N <= 2048, N % 16 == 0) reads the table with its channels interleaved in fours
-    static const bool valu = getenv("SVNET_KNN_MFMA") == nullptr;
+    static const bool valu = getenv("SVNET_KNN_MFMA") == nullptr && !SVNET_KNN_FORCE_MF;
     const int il4 = (N > 512 && N <= 2048 && (N & 15) == 0 && !valu) ? 1 : 0;
+    static const bool mf8_on = getenv("SVNET_KNN_NO_MF8") == nullptr && SVNET_KNN_MF8;
+    const bool mf8 = mf8_on && valu && N > 512 && N <= 1024 && (N & 15) == 0;     // knn_mf8_kernel: the table's clouds are C8 rows apart
     // one wave per workgroup: a thread walks its point's row, so every load instruction of a wave touches 64 cache lines - the kernel is
     // bound by the CUs' address units, and 32 768 points in 256-thread workgroups put four such waves on each of only 128 CUs (61 -> 47 us
     // for the four calls of a step; staging the rows through LDS with coalesced loads was slower - 33 us per call whatever C: one wave
     // per SIMD and two dependent phases leave nothing to overlap)
-    if (il4) hipLaunchKernelGGL(knn_prep_kernel<true>, dim3(svnet_grid(B * N, 64)), dim3(64), 0, st, x, B, N, C, sb, sn, sc, xx_mode, xT, xx, x2, split);
-    else hipLaunchKernelGGL(knn_prep_kernel<false>, dim3(svnet_grid(B * N, 64)), dim3(64), 0, st, x, B, N, C, sb, sn, sc, xx_mode, xT, xx, x2, split);
+    if (il4) hipLaunchKernelGGL(knn_prep_kernel<true>, dim3(svnet_grid(B * N, 64)), dim3(64), 0, st, x, B, N, C, sb, sn, sc, xx_mode, xT, xx, x2, split, C);
+    else hipLaunchKernelGGL(knn_prep_kernel<false>, dim3(svnet_grid(B * N, 64)), dim3(64), 0, st, x, B, N, C, sb, sn, sc, xx_mode, xT, xx, x2, split, mf8 ? C8 : C);
     SVNET_CHECK_LAUNCH("knn_prep_kernel");
     const int n = (int)N, c = (int)C;
     if (N <= 64) launch_main<1, 8>(xT, xx, B, n, c, k, idx_out, st);
     else if (N <= 128) launch_main<2, 8>(xT, xx, B, n, c, k, idx_out, st);
     else if (N <= 256) launch_main<4, 8>(xT, xx, B, n, c, k, idx_out, st);
     else if (N <= 512) launch_main<8, 8>(xT, xx, B, n, c, k, idx_out, st);
-    else if (N <= 1024) launch_main<16, 4>(xT, xx, B, n, c, k, idx_out, st);   // 4 queries per wave: <= 128 VGPRs, 4 waves per SIMD
+    else if (N <= 1024) launch_main<16, 4>(xT, xx, B, n, c, k, idx_out, st, mf8);   // 4 queries per wave: <= 128 VGPRs, 4 waves per SIMD
     else if (N <= 2048) launch_main<32, 4>(xT, xx, B, n, c, k, idx_out, st);
     else launch_main<64, 2>(xT, xx, B, n, c, k, idx_out, st);
     SVNET_CHECK_LAUNCH("knn_main_kernel");
