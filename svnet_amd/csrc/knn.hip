@@ -26,6 +26,12 @@
 #ifndef SVNET_KNN_MF8
 #define SVNET_KNN_MF8 1
 #endif
+#ifndef SVNET_KNN_NOSLOW
+#define SVNET_KNN_NOSLOW 0      // (diagnostic builds: the four-query selection without its one-at-a-time fall-back)
+#endif
+#ifndef SVNET_KNN_TP
+#define SVNET_KNN_TP 32
+#endif
 
 
 namespace {
@@ -53,6 +59,104 @@ struct Cascade {  // ATen multi_row_sum: 4 levels, level step 16
         return __fadd_rn(__fadd_rn(__fadd_rn(a0, a1), a2), a3);
     }
 };
+
+// The walk over one point's channels: ||x||^2 with ATen's exact recipe for the layout torch reduces (xx_mode), every value handed
+// to dst.put on the way (the transposition; a no-op for callers that transpose separately).
+template <class SrcT, class DstT>
+__device__ __forceinline__ float knn_xx_walk(const SrcT& src, const DstT& dst, int64_t C, int64_t N, int64_t n, int64_t sc, int xx_mode) {
+    float result;
+    if (xx_mode == 0) {
+        // outer-dim reduction: columns n < 32*floor(N/32) use one cascade, the rest ATen's row_sum (ilp 4)
+        if (n < (N / 32) * 32) {
+            Cascade cs;
+            for (int64_t c = 0; c < C; ++c) {
+                float v = src[c * sc];
+                dst.put(c, v);
+                cs.add(__fmul_rn(v, v));
+            }
+            result = cs.total();
+        } else {
+            Cascade part[4];
+            const int64_t ng = C / 4;
+            for (int64_t g = 0; g < ng; ++g) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = src[(4 * g + r) * sc];
+                    dst.put((4 * g + r), v);
+                    part[r].add(__fmul_rn(v, v));
+                }
+            }
+            float p0 = part[0].total(), p1 = part[1].total(), p2 = part[2].total(), p3 = part[3].total();
+            for (int64_t c = ng * 4; c < C; ++c) {
+                float v = src[c * sc];
+                dst.put(c, v);
+                p0 = __fadd_rn(p0, __fmul_rn(v, v));
+            }
+            result = __fadd_rn(__fadd_rn(__fadd_rn(p0, p1), p2), p3);
+        }
+    } else if (C < 8) {
+        // contiguous-dim reduction of a row shorter than one 8-lane vector: scalar row_sum (ilp 4)
+        float part[4] = {0.f, 0.f, 0.f, 0.f};
+        const int64_t ng = C / 4;
+        for (int64_t g = 0; g < ng; ++g) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = src[(4 * g + r) * sc];
+                dst.put((4 * g + r), v);
+                part[r] = __fadd_rn(part[r], __fmul_rn(v, v));
+            }
+        }
+        for (int64_t c = ng * 4; c < C; ++c) {
+            float v = src[c * sc];
+            dst.put(c, v);
+            part[0] = __fadd_rn(part[0], __fmul_rn(v, v));
+        }
+        result = __fadd_rn(__fadd_rn(__fadd_rn(part[0], part[1]), part[2]), part[3]);
+    } else {
+        // contiguous-dim reduction: 8-lane vectors, 4 interleaved vector accumulators (C <= 384 < 512,
+        // so the inner cascade never spills a level), leftover vectors into accumulator 0,
+        // lanes combined p0+p1+p2+p3, then scalar tail first, then the 8 lanes in order.
+        float p[4][8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) p[r][l] = 0.f;
+        const int64_t nv = C / 8, ng = nv / 4;
+        for (int64_t g = 0; g < ng; ++g) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int l = 0; l < 8; ++l) {
+                    const int64_t c = (4 * g + r) * 8 + l;
+                    float v = src[c * sc];
+                    dst.put(c, v);
+                    p[r][l] = __fadd_rn(p[r][l], __fmul_rn(v, v));
+                }
+        }
+        for (int64_t g = ng * 4; g < nv; ++g) {
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                const int64_t c = g * 8 + l;
+                float v = src[c * sc];
+                dst.put(c, v);
+                p[0][l] = __fadd_rn(p[0][l], __fmul_rn(v, v));
+            }
+        }
+        float fin = 0.f;
+        for (int64_t c = nv * 8; c < C; ++c) {
+            float v = src[c * sc];
+            dst.put(c, v);
+            fin = __fadd_rn(fin, __fmul_rn(v, v));
+        }
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            float lane = __fadd_rn(__fadd_rn(__fadd_rn(p[0][l], p[1][l]), p[2][l]), p[3][l]);
+            fin = __fadd_rn(fin, lane);
+        }
+        result = fin;
+    }
+    return result;
+}
 
 // One thread per point: transpose to channel-major and compute ||x||^2 with the exact recipe.
 // Two sources (x2 != nullptr): channel c < split comes from x, the rest from row p of x2 [B*N, C - split] - the feature rows
@@ -83,98 +187,55 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float* __restrict__
             }
         } dst = {xT + b * (il4 ? C4 : Cpad) * N, N, n};                              // (channel-major: Cpad >= C rows per cloud)
         for (int64_t c = C; c < (il4 ? C4 : Cpad); ++c) dst.put(c, 0.f);             // padding channels: zeros (never NaN bit patterns)
-        float result;
-        if (xx_mode == 0) {
-            // outer-dim reduction: columns n < 32*floor(N/32) use one cascade, the rest ATen's row_sum (ilp 4)
-            if (n < (N / 32) * 32) {
-                Cascade cs;
-                for (int64_t c = 0; c < C; ++c) {
-                    float v = src[c * sc];
-                    dst.put(c, v);
-                    cs.add(__fmul_rn(v, v));
-                }
-                result = cs.total();
-            } else {
-                Cascade part[4];
-                const int64_t ng = C / 4;
-                for (int64_t g = 0; g < ng; ++g) {
+        xx[p] = knn_xx_walk(src, dst, C, N, n, sc, xx_mode);
+    }
+}
+
+// Contiguous feature rows ([B*N, cut] (+ [B*N, C - cut]); N % 64 == 0): a thread walking its own row in global memory makes every load
+// of its wave touch 64 cache lines - the generic kernel is bound by the CUs' address units there (22 us at C = 127 for 16.6 MB).  Here a
+// 4-wave workgroup takes 64 consecutive points: their rows, one contiguous run per source, are copied into LDS with coalesced loads
+// (row stride C | 1: a lane per row is conflict-free), wave 0 walks them for ||x||^2 - same arithmetic, same order - and all four
+// waves write the channel-major table, 64 consecutive points of a channel per store instruction.
+template <int TP>   // points per tile (32 or 64): smaller tiles = more workgroups in flight; the kernel is a chain of latencies, not of bytes
+__global__ __launch_bounds__(256) void knn_prep_rows_kernel(const float* __restrict__ x, int64_t B, int64_t N, int64_t C, int xx_mode,
+                                                            float* __restrict__ xT, float* __restrict__ xx,
+                                                            const float* __restrict__ x2, int64_t split, int64_t Cpad) {
+    extern __shared__ float staged[];                                             // [TP][C | 1]
+    const int LD = (int)C | 1;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t tiles = B * N / TP;
+    const int cut = (int)(x2 ? split : C);
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t p0 = tile * TP;
+        if (tile != (int64_t)blockIdx.x) __syncthreads();                         // the previous tile has been read
+        for (int part = 0; part < (x2 ? 2 : 1); ++part) {
+            const int w = part ? (int)C - cut : cut, c0 = part ? cut : 0, total = TP * w;
+            const float* g = (part ? x2 : x) + p0 * w;
+            int row = tid / w, col = tid - row * w;
+            for (int i0 = 0; i0 < total; i0 += 256 * 16) {                        // sixteen coalesced loads in flight per thread
+                float v[16];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = src[(4 * g + r) * sc];
-                        dst.put((4 * g + r), v);
-                        part[r].add(__fmul_rn(v, v));
-                    }
-                }
-                float p0 = part[0].total(), p1 = part[1].total(), p2 = part[2].total(), p3 = part[3].total();
-                for (int64_t c = ng * 4; c < C; ++c) {
-                    float v = src[c * sc];
-                    dst.put(c, v);
-                    p0 = __fadd_rn(p0, __fmul_rn(v, v));
-                }
-                result = __fadd_rn(__fadd_rn(__fadd_rn(p0, p1), p2), p3);
-            }
-        } else if (C < 8) {
-            // contiguous-dim reduction of a row shorter than one 8-lane vector: scalar row_sum (ilp 4)
-            float part[4] = {0.f, 0.f, 0.f, 0.f};
-            const int64_t ng = C / 4;
-            for (int64_t g = 0; g < ng; ++g) {
+                for (int u = 0; u < 16; ++u) { const int i = i0 + 256 * u + tid; v[u] = i < total ? g[i] : 0.f; }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = src[(4 * g + r) * sc];
-                    dst.put((4 * g + r), v);
-                    part[r] = __fadd_rn(part[r], __fmul_rn(v, v));
+                for (int u = 0; u < 16; ++u) {
+                    if (i0 + 256 * u + tid < total) staged[row * LD + c0 + col] = v[u];
+                    col += 256;
+                    while (col >= w) { col -= w; ++row; }
                 }
             }
-            for (int64_t c = ng * 4; c < C; ++c) {
-                float v = src[c * sc];
-                dst.put(c, v);
-                part[0] = __fadd_rn(part[0], __fmul_rn(v, v));
-            }
-            result = __fadd_rn(__fadd_rn(__fadd_rn(part[0], part[1]), part[2]), part[3]);
-        } else {
-            // contiguous-dim reduction: 8-lane vectors, 4 interleaved vector accumulators (C <= 384 < 512,
-            // so the inner cascade never spills a level), leftover vectors into accumulator 0,
-            // lanes combined p0+p1+p2+p3, then scalar tail first, then the 8 lanes in order.
-            float p[4][8];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int l = 0; l < 8; ++l) p[r][l] = 0.f;
-            const int64_t nv = C / 8, ng = nv / 4;
-            for (int64_t g = 0; g < ng; ++g) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int l = 0; l < 8; ++l) {
-                        const int64_t c = (4 * g + r) * 8 + l;
-                        float v = src[c * sc];
-                        dst.put(c, v);
-                        p[r][l] = __fadd_rn(p[r][l], __fmul_rn(v, v));
-                    }
-            }
-            for (int64_t g = ng * 4; g < nv; ++g) {
-#pragma unroll
-                for (int l = 0; l < 8; ++l) {
-                    const int64_t c = g * 8 + l;
-                    float v = src[c * sc];
-                    dst.put(c, v);
-                    p[0][l] = __fadd_rn(p[0][l], __fmul_rn(v, v));
-                }
-            }
-            float fin = 0.f;
-            for (int64_t c = nv * 8; c < C; ++c) {
-                float v = src[c * sc];
-                dst.put(c, v);
-                fin = __fadd_rn(fin, __fmul_rn(v, v));
-            }
-#pragma unroll
-            for (int l = 0; l < 8; ++l) {
-                float lane = __fadd_rn(__fadd_rn(__fadd_rn(p[0][l], p[1][l]), p[2][l]), p[3][l]);
-                fin = __fadd_rn(fin, lane);
-            }
-            result = fin;
         }
-        xx[p] = result;
+        __syncthreads();
+        const int64_t b = p0 / N, n0 = p0 - b * N;
+        if (wave == 0 && lane < TP) {
+            struct Src { const float* a; __device__ __forceinline__ float operator[](int64_t off) const { return a[off]; } } src = {staged + lane * LD};
+            struct Dst { __device__ __forceinline__ void put(int64_t, float) const {} } dst;
+            xx[p0 + lane] = knn_xx_walk(src, dst, C, N, n0 + lane, 1, xx_mode);
+        }
+        // the channel-major table: TP consecutive points of a channel per store instruction (64 / TP channels per wave and instruction)
+        constexpr int CPI = 64 / TP;
+        const int pl = lane % TP, cl = lane / TP;
+        float* out = xT + (size_t)b * Cpad * N + n0 + pl;
+        for (int c = wave * CPI + cl; c < (int)Cpad; c += 4 * CPI) out[(size_t)c * N] = c < (int)C ? staged[pl * LD + c] : 0.f;   // (rows past C: zeros)
     }
 }
 
@@ -197,7 +258,7 @@ __device__ __forceinline__ bool ranks_before(float va, int ja, float vb, int jb)
 // (a bitonic sort is a chain of 21 dependent exchanges, so the ~100-cycle ds_bpermute round trip was its whole cost).
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_u32(uint32_t x) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, true);      // (every lane has a source: bound_ctrl only spares the v_mov of "old")
 }
 template <int S>
 __device__ __forceinline__ uint32_t lane_xor_u32(uint32_t x, int lane) {
@@ -269,6 +330,31 @@ __device__ __forceinline__ void sort_step_pair(uint32_t& hi, uint32_t& lo, int l
     hi = take ? ohi : hi;
     lo = take ? olo : lo;
 }
+// The same exchanges with the direction folded into the DATA: during stage K2 the lanes of the ascending blocks (lane & K2) hold the
+// COMPLEMENT of their key, so that every block sorts the same way - the lower lane of a pair keeps the larger word, the upper lane the
+// smaller - and the lane pattern of an exchange depends on its distance S2 alone: 6 patterns instead of 21 (with four networks side
+// by side the 21 live scalar pairs no longer fitted: 168 v_writelane / v_readlane per four queries).  xform<K2>() moves the data from
+// stage K2 / 2's form to stage K2's (one exclusive-or with a lane constant); stage 64 has no ascending blocks, so the network ends
+// on the plain keys.
+template <int K2>
+__device__ __forceinline__ uint32_t stage_mask(int lane) {            // complemented lanes of stage K2 (none for K2 = 64 and before the first stage)
+    return (K2 >= 64 || K2 < 2) ? 0u : (uint32_t)(0 - ((lane / K2) & 1));
+}
+template <int K2>
+__device__ __forceinline__ uint32_t xform(int lane) { return stage_mask<K2 / 2>(lane) ^ stage_mask<K2>(lane); }   // (K2 = 2: from the plain keys)
+template <int S2>
+__device__ __forceinline__ void cx_key(uint32_t& key, int lane) {
+    const uint32_t ok = lane_xor_u32<S2>(key, lane);
+    const bool take = (ok > key) != ((lane & S2) != 0);
+    key = take ? ok : key;
+}
+template <int S2>
+__device__ __forceinline__ void cx_pair(uint32_t& hi, uint32_t& lo, int lane) {
+    const uint32_t ohi = lane_xor_u32<S2>(hi, lane), olo = lane_xor_u32<S2>(lo, lane);
+    const bool take = ((((uint64_t)ohi << 32) | olo) > (((uint64_t)hi << 32) | lo)) != ((lane & S2) != 0);
+    hi = take ? ohi : hi;
+    lo = take ? olo : lo;
+}
 #define SVNET_SORT_NETWORK(STEP, ...)                                                                                            \
     STEP<2, 1>(__VA_ARGS__);                                                                                                      \
     STEP<4, 2>(__VA_ARGS__); STEP<4, 1>(__VA_ARGS__);                                                                             \
@@ -283,6 +369,85 @@ __device__ __forceinline__ void wave_sort_pairs(uint32_t& hi, uint32_t& lo, int 
 
 // Selection: a wave holds the inner products of Q queries with ALL the cloud's candidates (candidate j = lane + 64 t in acc[q][t]),
 // turns them into pd(i, j) and writes the k first-ranked ids of each query.  cand_v / cand_j: this wave's CAP slots of LDS.
+template <int T>
+__device__ __forceinline__ void knn_pd(float (&row)[T], const float (&xxj)[T], float xxi, int N, int lane) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int j = lane + 64 * t;
+        const float inner = -2.0f * row[t];                    // exact
+        const float t1 = __fsub_rn(-xxj[t], inner);            // fl(-xx[j] - inner)
+        const float v = __fsub_rn(t1, xxi);                    // fl(.. - xx[i])
+        row[t] = (j < N) ? v : -INFINITY;
+    }
+}
+// one query: pd[t] = distance to candidate lane + 64 t; returns this lane's neighbour id (lane s: the s-th ranked)
+template <int T, int CAP>
+__device__ __forceinline__ int knn_select_one(float (&pd)[T], int k, int lane, float* cand_v, int* cand_j) {
+// ---- top-k selection.  Threshold pass: the k-th largest of the 64 lane maxima is a lower bound of the k-th
+    // largest distance, so every winner is >= it; those few candidates (typically < 2k) are compacted into LDS
+    // with ballot prefix sums and sorted across the wave.  If more than 64 qualify (heavy ties) fall back to k
+    // rounds of wave-wide arg-max.
+    int mine = 0;
+    float lm = pd[0];
+#pragma unroll
+    for (int t = 1; t < T; ++t) lm = fmaxf(lm, pd[t]);
+    {
+        uint32_t key = ord_key(lm);
+        wave_sort_keys(key, lane);
+        lm = ord_val((uint32_t)__shfl((int)key, k - 1, 64));   // threshold (wave-uniform): the k-th largest lane maximum
+    }
+    int count = 0;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const bool in = pd[t] >= lm;
+        const uint64_t m = __ballot(in);
+        const int pos = count + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (in && pos < CAP) {
+            cand_v[pos] = pd[t];
+            cand_j[pos] = lane + 64 * t;
+        }
+        count += __popcll(m);
+    }
+    if (count <= CAP) {  // wave-uniform
+        const float cv = (lane < count) ? cand_v[lane] : -INFINITY;
+        const int cj = (lane < count) ? cand_j[lane] : 0x7fffffff;
+        uint32_t hi = ord_key(cv), lo = ~(uint32_t)cj;
+        wave_sort_pairs(hi, lo, lane);
+        // More than 64 qualified (k close to 64: the k-th largest of 64 lane maxima is a weak bound - at N = 2048, k = 40 the
+        // expected count is 62): every further chunk of 64 is sorted the same way and merged in - max(A[i], B[63 - i]) of two
+        // descending runs holds the 64 first-ranked of their union as a bitonic sequence, which the last stage of the network sorts.
+        for (int c0 = 64; c0 < count; c0 += 64) {
+            const float cv2 = (c0 + lane < count) ? cand_v[c0 + lane] : -INFINITY;
+            const int cj2 = (c0 + lane < count) ? cand_j[c0 + lane] : 0x7fffffff;
+            uint32_t hi2 = ord_key(cv2), lo2 = ~(uint32_t)cj2;
+            wave_sort_pairs(hi2, lo2, lane);
+            const uint32_t rh = (uint32_t)__shfl((int)hi2, 63 - lane, 64), rl = (uint32_t)__shfl((int)lo2, 63 - lane, 64);
+            const bool take = ((((uint64_t)rh << 32) | rl) > (((uint64_t)hi << 32) | lo));
+            hi = take ? rh : hi;
+            lo = take ? rl : lo;
+            sort_step_pair<64, 32>(hi, lo, lane); sort_step_pair<64, 16>(hi, lo, lane); sort_step_pair<64, 8>(hi, lo, lane);
+            sort_step_pair<64, 4>(hi, lo, lane); sort_step_pair<64, 2>(hi, lo, lane); sort_step_pair<64, 1>(hi, lo, lane);
+        }
+        mine = (int)~lo;
+    } else {
+        for (int s = 0; s < k; ++s) {
+            float bv = pd[0];
+            int bt = 0;
+#pragma unroll
+            for (int t = 1; t < T; ++t) {
+                const bool g = pd[t] > bv;  // strict: first (lowest j) wins inside a lane
+                bv = g ? pd[t] : bv;
+                bt = g ? t : bt;
+            }
+            int bj = lane + 64 * bt;
+            wave_argmax(bv, bj);
+            if (lane == s) mine = bj;
+#pragma unroll
+            for (int t = 0; t < T; ++t) pd[t] = (bj == lane + 64 * t) ? -INFINITY : pd[t];
+        }
+    }
+    return mine;
+}
 template <int T, int Q, int CAP>
 __device__ __forceinline__ void knn_select(float (&acc)[Q][T], const float* __restrict__ xxb, int N, int k, int lane, float* cand_v, int* cand_j,
                                            const int (&qid)[Q], int64_t* __restrict__ idx_cloud) {
@@ -292,85 +457,141 @@ __device__ __forceinline__ void knn_select(float (&acc)[Q][T], const float* __re
         const int j = lane + 64 * t;
         xxj[t] = (j < N) ? xxb[j] : 0.f;
     }
-
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         if (qid[q] >= N) continue;  // wave-uniform
-        const float xxi = xxb[qid[q]];
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int j = lane + 64 * t;
-            const float inner = -2.0f * acc[q][t];                 // exact
-            const float t1 = __fsub_rn(-xxj[t], inner);            // fl(-xx[j] - inner)
-            const float pd = __fsub_rn(t1, xxi);                   // fl(.. - xx[i])
-            acc[q][t] = (j < N) ? pd : -INFINITY;
-        }
-        // ---- top-k selection.  Threshold pass: the k-th largest of the 64 lane maxima is a lower bound of the k-th
-        // largest distance, so every winner is >= it; those few candidates (typically < 2k) are compacted into LDS
-        // with ballot prefix sums and sorted across the wave.  If more than 64 qualify (heavy ties) fall back to k
-        // rounds of wave-wide arg-max.
-        int mine = 0;
-        float lm = acc[q][0];
-#pragma unroll
-        for (int t = 1; t < T; ++t) lm = fmaxf(lm, acc[q][t]);
-        {
-            uint32_t key = ord_key(lm);
-            wave_sort_keys(key, lane);
-            lm = ord_val((uint32_t)__shfl((int)key, k - 1, 64));   // threshold (wave-uniform): the k-th largest lane maximum
-        }
-        int count = 0;
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const bool in = acc[q][t] >= lm;
-            const uint64_t m = __ballot(in);
-            const int pos = count + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (in && pos < CAP) {
-                cand_v[pos] = acc[q][t];
-                cand_j[pos] = lane + 64 * t;
-            }
-            count += __popcll(m);
-        }
-        if (count <= CAP) {  // wave-uniform
-            const float cv = (lane < count) ? cand_v[lane] : -INFINITY;
-            const int cj = (lane < count) ? cand_j[lane] : 0x7fffffff;
-            uint32_t hi = ord_key(cv), lo = ~(uint32_t)cj;
-            wave_sort_pairs(hi, lo, lane);
-            // More than 64 qualified (k close to 64: the k-th largest of 64 lane maxima is a weak bound - at N = 2048, k = 40 the
-            // expected count is 62): every further chunk of 64 is sorted the same way and merged in - max(A[i], B[63 - i]) of two
-            // descending runs holds the 64 first-ranked of their union as a bitonic sequence, which the last stage of the network sorts.
-            for (int c0 = 64; c0 < count; c0 += 64) {
-                const float cv2 = (c0 + lane < count) ? cand_v[c0 + lane] : -INFINITY;
-                const int cj2 = (c0 + lane < count) ? cand_j[c0 + lane] : 0x7fffffff;
-                uint32_t hi2 = ord_key(cv2), lo2 = ~(uint32_t)cj2;
-                wave_sort_pairs(hi2, lo2, lane);
-                const uint32_t rh = (uint32_t)__shfl((int)hi2, 63 - lane, 64), rl = (uint32_t)__shfl((int)lo2, 63 - lane, 64);
-                const bool take = ((((uint64_t)rh << 32) | rl) > (((uint64_t)hi << 32) | lo));
-                hi = take ? rh : hi;
-                lo = take ? rl : lo;
-                sort_step_pair<64, 32>(hi, lo, lane); sort_step_pair<64, 16>(hi, lo, lane); sort_step_pair<64, 8>(hi, lo, lane);
-                sort_step_pair<64, 4>(hi, lo, lane); sort_step_pair<64, 2>(hi, lo, lane); sort_step_pair<64, 1>(hi, lo, lane);
-            }
-            mine = (int)~lo;
-        } else {
-            for (int s = 0; s < k; ++s) {
-                float bv = acc[q][0];
-                int bt = 0;
-#pragma unroll
-                for (int t = 1; t < T; ++t) {
-                    const bool g = acc[q][t] > bv;  // strict: first (lowest j) wins inside a lane
-                    bv = g ? acc[q][t] : bv;
-                    bt = g ? t : bt;
-                }
-                int bj = lane + 64 * bt;
-                wave_argmax(bv, bj);
-                if (lane == s) mine = bj;
-#pragma unroll
-                for (int t = 0; t < T; ++t) acc[q][t] = (bj == lane + 64 * t) ? -INFINITY : acc[q][t];
-            }
-        }
+        knn_pd<T>(acc[q], xxj, xxb[qid[q]], N, lane);
+        const int mine = knn_select_one<T, CAP>(acc[q], k, lane, cand_v, cand_j);
         // (NaN distances compare false everywhere and can leave slots unfilled: never hand an out-of-range id to the gathers)
         if (lane < k) idx_cloud[(size_t)qid[q] * k + lane] = ((unsigned)mine < (unsigned)N) ? mine : qid[q];
     }
+}
+
+// Inclusive prefix sum of one integer per lane across the wave: four shifts inside the 16-lane rows, then the row totals are carried
+// over with the two row broadcasts (DPP modifiers of the adds; lanes without a source add 0).
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);    // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// Four queries at once.  The steps are those of knn_select_one; what changes is how they are issued:
+//  * the four queries' sorting networks run side by side, stage by stage - a network is a chain of 21 dependent exchanges, each a DPP move
+//    that has to wait two cycles for the select before it (481 s_nop in the one-at-a-time form) - four independent chains fill those slots;
+//  * the candidates >= the threshold are compacted lane-locally: a lane counts its own, ONE prefix sum over the lanes gives it its first
+//    slot, and it writes its candidates there one after the other (a select of the address, not an exec-mask branch, keeps the lanes
+//    that have none out: they write to a slot of their own behind the list) - the ballot / mbcnt / s_bcnt1 / branch per register of the
+//    old form was 12 instructions per candidate register, half of them scalar;
+//  * a query with more than 64 candidates (heavy ties, k near 64) sends all four through knn_select_one.
+// scratch: 4 x 2 x SVNET_KNN_SLOTS words of this wave's LDS.
+constexpr int SVNET_KNN_SLOTS = 192;        // 64 list slots + 64 lanes' spare slots (+ 64: knn_select_one's 128)
+template <int T>
+__device__ __forceinline__ void knn_select4(float (&acc)[4][T], const float* __restrict__ xxb, int N, int k, int lane, float* scratch,
+                                            const int (&qid)[4], int64_t* __restrict__ idx_cloud) {
+    float xxj[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int j = lane + 64 * t;
+        xxj[t] = (j < N) ? xxb[j] : 0.f;
+    }
+    uint32_t key[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        knn_pd<T>(acc[q], xxj, xxb[min(qid[q], N - 1)], N, lane);
+        float lm = acc[q][0];
+#pragma unroll
+        for (int t = 1; t < T; ++t) lm = fmaxf(lm, acc[q][t]);
+        key[q] = ord_key(lm);
+    }
+#define SVNET_X4_KEY(K2) do { const uint32_t m_ = xform<K2>(lane); key[0] ^= m_; key[1] ^= m_; key[2] ^= m_; key[3] ^= m_; } while (0)
+#define SVNET_CX4_KEY(S2) do { cx_key<S2>(key[0], lane); cx_key<S2>(key[1], lane); cx_key<S2>(key[2], lane); cx_key<S2>(key[3], lane); } while (0)
+    SVNET_X4_KEY(2); SVNET_CX4_KEY(1);
+    SVNET_X4_KEY(4); SVNET_CX4_KEY(2); SVNET_CX4_KEY(1);
+    SVNET_X4_KEY(8); SVNET_CX4_KEY(4); SVNET_CX4_KEY(2); SVNET_CX4_KEY(1);
+    SVNET_X4_KEY(16); SVNET_CX4_KEY(8); SVNET_CX4_KEY(4); SVNET_CX4_KEY(2); SVNET_CX4_KEY(1);
+    SVNET_X4_KEY(32); SVNET_CX4_KEY(16); SVNET_CX4_KEY(8); SVNET_CX4_KEY(4); SVNET_CX4_KEY(2); SVNET_CX4_KEY(1);
+    SVNET_X4_KEY(64); SVNET_CX4_KEY(32); SVNET_CX4_KEY(16); SVNET_CX4_KEY(8); SVNET_CX4_KEY(4); SVNET_CX4_KEY(2); SVNET_CX4_KEY(1);
+#undef SVNET_X4_KEY
+#undef SVNET_CX4_KEY
+    float thr[4];
+    int pos[4], total[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        thr[q] = ord_val((uint32_t)__builtin_amdgcn_readlane((int)key[q], k - 1));     // the k-th largest lane maximum (wave-uniform)
+        int cnt = 0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) cnt += (acc[q][t] >= thr[q]) ? 1 : 0;
+        const int incl = wave_incl_scan(cnt);
+        total[q] = __builtin_amdgcn_readlane(incl, 63);
+        pos[q] = incl - cnt;
+    }
+    const int most = max(max(total[0], total[1]), max(total[2], total[3]));
+    int mine[4];
+    if (most <= 64) {   // (wave-uniform)
+        uint32_t hi[4], lo[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float* sv = scratch + q * 2 * SVNET_KNN_SLOTS;
+            int* sj = reinterpret_cast<int*>(sv + SVNET_KNN_SLOTS);
+            int at = pos[q];
+            float th = thr[q];
+            asm volatile("" : "+s"(th));                                 // (or the 64 compares of the counting pass are kept alive as scalar pairs, spilled lane by lane)
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const bool in = acc[q][t] >= th;
+                const int slot = in ? at : 64 + lane;
+                sv[slot] = acc[q][t];
+                sj[slot] = lane + 64 * t;
+                at += in ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float* sv = scratch + q * 2 * SVNET_KNN_SLOTS;
+            const int* sj = reinterpret_cast<const int*>(sv + SVNET_KNN_SLOTS);
+            const float cv = sv[lane];
+            const int cj = sj[lane];
+            hi[q] = ord_key((lane < total[q]) ? cv : -INFINITY);
+            lo[q] = ~(uint32_t)((lane < total[q]) ? cj : 0x7fffffff);
+        }
+#define SVNET_X4_PAIR(K2) do { const uint32_t m_ = xform<K2>(lane); _Pragma("unroll") for (int q = 0; q < 4; ++q) { hi[q] ^= m_; lo[q] ^= m_; } } while (0)
+#define SVNET_CX4_PAIR(S2) do { cx_pair<S2>(hi[0], lo[0], lane); cx_pair<S2>(hi[1], lo[1], lane); cx_pair<S2>(hi[2], lo[2], lane); cx_pair<S2>(hi[3], lo[3], lane); } while (0)
+        SVNET_X4_PAIR(2); SVNET_CX4_PAIR(1);
+        SVNET_X4_PAIR(4); SVNET_CX4_PAIR(2); SVNET_CX4_PAIR(1);
+        SVNET_X4_PAIR(8); SVNET_CX4_PAIR(4); SVNET_CX4_PAIR(2); SVNET_CX4_PAIR(1);
+        SVNET_X4_PAIR(16); SVNET_CX4_PAIR(8); SVNET_CX4_PAIR(4); SVNET_CX4_PAIR(2); SVNET_CX4_PAIR(1);
+        SVNET_X4_PAIR(32); SVNET_CX4_PAIR(16); SVNET_CX4_PAIR(8); SVNET_CX4_PAIR(4); SVNET_CX4_PAIR(2); SVNET_CX4_PAIR(1);
+        SVNET_X4_PAIR(64); SVNET_CX4_PAIR(32); SVNET_CX4_PAIR(16); SVNET_CX4_PAIR(8); SVNET_CX4_PAIR(4); SVNET_CX4_PAIR(2); SVNET_CX4_PAIR(1);
+#undef SVNET_X4_PAIR
+#undef SVNET_CX4_PAIR
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mine[q] = (int)~lo[q];
+    } else {
+        // (rare: ONE copy of the one-at-a-time code, walked by a loop that is not unrolled, and fed through LDS - it takes a query's
+        //  distances from this wave's 4 KB, not from the accumulator registers: four inlined copies reading the registers cost the
+        //  common path 6 - 9 us per call in spilled registers)
+        mine[0] = mine[1] = mine[2] = mine[3] = 0;
+        float* row = scratch + 2 * SVNET_KNN_SLOTS;                      // [64 T] behind knn_select_one's 128 + 128 slots (at T = 16: 6 KB of the wave's 6)
+#pragma unroll 1
+        for (int q = 0; q < (SVNET_KNN_NOSLOW ? 0 : 4); ++q) {
+            if (q == 0) { _Pragma("unroll") for (int t = 0; t < T; ++t) row[64 * t + lane] = acc[0][t]; }
+            else if (q == 1) { _Pragma("unroll") for (int t = 0; t < T; ++t) row[64 * t + lane] = acc[1][t]; }
+            else if (q == 2) { _Pragma("unroll") for (int t = 0; t < T; ++t) row[64 * t + lane] = acc[2][t]; }
+            else { _Pragma("unroll") for (int t = 0; t < T; ++t) row[64 * t + lane] = acc[3][t]; }
+            float pd[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) pd[t] = row[64 * t + lane];
+            const int m = knn_select_one<T, 128>(pd, k, lane, scratch, reinterpret_cast<int*>(scratch + SVNET_KNN_SLOTS));
+            mine[0] = q == 0 ? m : mine[0]; mine[1] = q == 1 ? m : mine[1]; mine[2] = q == 2 ? m : mine[2]; mine[3] = q == 3 ? m : mine[3];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)   // (NaN distances compare false everywhere and can leave slots unfilled: never hand an out-of-range id to the gathers)
+        if (qid[q] < N && lane < k) idx_cloud[(size_t)qid[q] * k + lane] = ((unsigned)mine[q] < (unsigned)N) ? mine[q] : qid[q];
 }
 
 // T candidates per lane (64*T >= N), Q query rows per wave, 4 waves per workgroup.
@@ -707,10 +928,7 @@ __global__ __launch_bounds__(512, 4) void knn_mf8_kernel(const float* __restrict
     constexpr int WPB = 8, QB = 32, Q = 4;
     constexpr int CW = NP / WPB;               // candidates per wave in the distance phase
     constexpr int NTL = CW / 16;               // 16-candidate tiles per wave
-    constexpr int CAP = T >= 32 ? 256 : 128;
-    static_assert(16 * LDS_H <= NB * KC * LDS_S, "the hand-over fits in the staging buffers");
-    __shared__ float cand_v[WPB * CAP];
-    __shared__ int cand_j[WPB * CAP];
+    static_assert(16 * LDS_H <= NB * KC * LDS_S && WPB * 8 * SVNET_KNN_SLOTS <= NB * KC * LDS_S && 2 * SVNET_KNN_SLOTS + 64 * T <= 8 * SVNET_KNN_SLOTS, "the hand-over and the selection's lists fit in the staging buffers");
     extern __shared__ __attribute__((aligned(16))) float rows[];          // [NB][KC][LDS_S]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -730,7 +948,8 @@ __global__ __launch_bounds__(512, 4) void knn_mf8_kernel(const float* __restrict
     // barrier that ended step s - 1), k-step s + 2 is in flight, k-step s's operands are in registers.  Step s then requests k-step s + 3
     // (into the buffer whose operands were read during step s - 2), reads the operands of s + 1 and issues the products of s - nothing
     // in it waits for a round trip.  Every wave issues DMA_PER instructions per k-step whatever N is (columns past N: a clamped source),
-    // so that the counted wait means the same in all of them.
+    // so that the counted wait means the same in all of them; a run that starts before N and ends past it reads on into the next row
+    // (the table is followed by the ||x||^2 array: always mapped), and what lands past column N only reaches distances the selection masks.
     const int C8 = (C + 7) / 8 * 8;
     const float* __restrict__ xb8 = xT + (size_t)b * C8 * N;
     typedef __attribute__((address_space(3))) float lds_f32;
@@ -744,7 +963,7 @@ __global__ __launch_bounds__(512, 4) void knn_mf8_kernel(const float* __restrict
         float* buf_ = rows + ((S) & (NB - 1)) * (KC * LDS_S);                                       \
         _Pragma("unroll") for (int u = 0; u < DMA_PER; ++u) {                                       \
             const int e_ = wave * DMA_PER + u, rw_ = e_ / (NP / 256), i_ = e_ - rw_ * (NP / 256);  \
-            __builtin_amdgcn_global_load_lds((glb_f32*)(xb8 + (size_t)(4 * s_ + rw_) * N + min(256 * i_, N - 256) + 4 * lane),     \
+            __builtin_amdgcn_global_load_lds((glb_f32*)(xb8 + (size_t)(4 * s_ + rw_) * N + (256 * i_ < N ? 256 * i_ : N - 256) + 4 * lane),     \
                                              (lds_f32*)(buf_ + rw_ * LDS_S + 256 * i_), 16, 0, 0);                                  \
         }                                                                                           \
     } while (0)
@@ -832,7 +1051,8 @@ __global__ __launch_bounds__(512, 4) void knn_mf8_kernel(const float* __restrict
         return;
     }
 #endif
-    knn_select<T, Q, CAP>(acc, xxb, N, k, lane, cand_v + wave * CAP, cand_j + wave * CAP, qid, idx_out + (size_t)b * N * k);
+    __syncthreads();                                                     // the hand-over has been read: its LDS now holds the selection's lists
+    knn_select4<T>(acc, xxb, N, k, lane, rows + wave * (8 * SVNET_KNN_SLOTS), qid, idx_out + (size_t)b * N * k);
 }
 
 template <int T, int Q>
@@ -923,7 +1143,13 @@ static int knn_impl(const float* x, const float* x2, int64_t split, int64_t B, i
     // bound by the CUs' address units, and 32 768 points in 256-thread workgroups put four such waves on each of only 128 CUs (61 -> 47 us
     // for the four calls of a step; staging the rows through LDS with coalesced loads was slower - 33 us per call whatever C: one wave
     // per SIMD and two dependent phases leave nothing to overlap)
+    // (ROWS: see the kernel; the channel-first coordinate graph - sn == 1 - is coalesced as it is)
+    const int64_t cut = x2 ? split : C;
+    static const bool rows_on = getenv("SVNET_KNN_NO_ROWS") == nullptr;
+    const bool rows = rows_on && !il4 && sc == 1 && sn == cut && sb == N * cut && (N & 63) == 0 && C >= 96 && C <= 255;   // (below ~96 channels the generic kernel is as fast: 11 us either way at C = 62)
     if (il4) hipLaunchKernelGGL(knn_prep_kernel<true>, dim3(svnet_grid(B * N, 64)), dim3(64), 0, st, x, B, N, C, sb, sn, sc, xx_mode, xT, xx, x2, split, C);
+    else if (rows) hipLaunchKernelGGL(knn_prep_rows_kernel<SVNET_KNN_TP>, dim3(svnet_grid(B * N / SVNET_KNN_TP, 1)), dim3(256),
+                                      (size_t)SVNET_KNN_TP * ((size_t)C | 1) * sizeof(float), st, x, B, N, C, xx_mode, xT, xx, x2, split, mf8 ? C8 : C);
     else hipLaunchKernelGGL(knn_prep_kernel<false>, dim3(svnet_grid(B * N, 64)), dim3(64), 0, st, x, B, N, C, sb, sn, sc, xx_mode, xT, xx, x2, split, mf8 ? C8 : C);
     SVNET_CHECK_LAUNCH("knn_prep_kernel");
     const int n = (int)N, c = (int)C;

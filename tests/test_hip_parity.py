@@ -61,7 +61,11 @@ def test_knn_bit_exact(case, hip_device):
                                    (8, 1024, 62, 20, "nc"), (8, 1024, 127, 20, "nc"), (32, 1024, 62, 20, "nc"), (32, 1024, 127, 20, "nc"),
                                    (32, 1024, 3, 20, "cn"), (16, 2048, 80, 40, "nc"), (8, 512, 62, 20, "nc"),
                                    # N % 16 != 0 at N <= 1024: the staged (non-split) form; N % 4 != 0: the unstaged form
-                                   (2, 1000, 62, 20, "nc"), (8, 1000, 127, 20, "nc"), (2, 1001, 30, 20, "nc"), (3, 600, 16, 12, "nc")])
+                                   (2, 1000, 62, 20, "nc"), (8, 1000, 127, 20, "nc"), (2, 1001, 30, 20, "nc"), (3, 600, 16, 12, "nc"),
+                                   # 512 < N < 1024, N % 16 == 0: the matrix-core form with staged columns past N (clamped DMA sources), a last
+                                   # workgroup of 16 queries (N % 32 != 0), k up to 64 (the four-query selection's one-at-a-time fall-back)
+                                   (8, 768, 62, 20, "nc"), (2, 528, 30, 20, "nc"), (8, 1008, 127, 20, "nc"), (2, 1024, 5, 64, "nc"),
+                                   (3, 1024, 131, 33, "nc")])
 def test_knn_bit_exact_more_shapes(shape, hip_device):
     from svnet_amd.models.utils.sv_util import knn
     B, N, Cc, k, layout = shape
@@ -73,7 +77,9 @@ def test_knn_bit_exact_more_shapes(shape, hip_device):
 
 
 @pytest.mark.parametrize("N,C_,k,dup", [(256, 12, 20, 100), (1024, 62, 20, 300), (1000, 9, 16, 70), (2048, 20, 40, 129),
-                                        (1024, 62, 20, 100), (2048, 20, 40, 300), (2048, 7, 40, 200)])
+                                        (1024, 62, 20, 100), (2048, 20, 40, 300), (2048, 7, 40, 200),
+                                        # N = 1024: ties inside the four-query selection's 64 slots, just past them, in a short table
+                                        (1024, 62, 20, 60), (1024, 3, 20, 66), (768, 62, 20, 70), (1024, 127, 20, 30)])
 def test_knn_heavy_ties_take_the_lowest_index(N, C_, k, dup, hip_device):
     """`dup` copies of one point: more than 64 candidates tie with the k-th distance.  Up to the kernel's candidate slots (64 / 128 /
     256 per query at N <= 512 / 1024 / 2048) they take its sort-and-merge selection, beyond that the fallback (k passes of wave
