@@ -47,9 +47,22 @@ int svnet_slices_sum_f64(double* buf, int64_t L, void* stream);
  * changes its required length (200: sliced accumulators, SVNET_SLICED_LEN; 400: this header; 401: the totals of a sliced accumulator are
  * written by its consumer, svnet_slices_sum_*; 402: GX of svnet_v2s_bwd_*, gw of svnet_xyzblock_bwd_f32 and col_sum of svnet_gemm_f32 are sliced accumulators; 403: svnet_binweight_grad_f32 takes sliced inputs).  svnet_version() returns the value the
  * library was BUILT with: a caller compiled against another header must refuse to run (svnet_amd/_lib.py does).                   */
-#define SVNET_ABI_VERSION 403
+#define SVNET_ABI_VERSION 404
 int svnet_version(void);
 const char* svnet_last_error(void);
+
+/* A gate MLP run by extra workgroups of a coefficient launch (svnet_edgeblock_coeffs_f32, svnet_xyzblock_coeffs_f32,
+ * svnet_edgeblock_bwd_coeffs_f32: their last argument, NULL = none): the arguments of svnet_gate_mlp_fwd_f32 / svnet_gate_mlp_bwd_f32
+ * below.  The gate and the coefficients only share their inputs; as two launches they were two latency-bound links of every fused
+ * layer's critical path. */
+typedef struct svnet_gate_fwd_job {
+    const float* gin; const double* gin_f64; float* gin_out; float in_scale; const float* W0; const float* W2;
+    int64_t B, Cin, H, Ov; float* h; float* gate;
+} svnet_gate_fwd_job;
+typedef struct svnet_gate_bwd_job {
+    const float* dgate; const float* gate; const float* h; const float* gin; float in_scale; const float* W0; const float* W2;
+    int64_t B, Cin, H, Ov; float out_scale; float* dgin; float* dW0; float* dW2;
+} svnet_gate_bwd_job;
 
 /* ------------------------------------------------------------------ k-NN  (models/utils/sv_util.py:19-25, knn)
  * x is addressed as x[b*sb + n*sn + c*sc] (the [B,C,N] tensor the reference passes, any strides).
@@ -193,7 +206,7 @@ int svnet_edgeblock_coeffs_f32(const int64_t* stat_n, const double* stat_v, int6
                                float* running_var1, const float* gamma2, const float* beta2, float* running_mean2,
                                float* running_var2, int training, float eps, float momentum, float* coef,
                                int64_t* num_batches_tracked1, int64_t* num_batches_tracked2 /* += 1 when training; may be NULL */,
-                               void* stream);
+                               const svnet_gate_fwd_job* gate_job /* may be NULL */, void* stream);
 /* s_out[P,Os] = leaky_relu(A1*(A1>=0 ? n_max : n_min) + B1);  v_out[P,3,Ov] = gate[b]*(Av*mv + Bv*mvn).
  * s_cat / v_cat (each may be NULL): the same values written a second time as a column slice of wider rows - s_cat[p*s_ld + o],
  * v_cat[(p*3 + d)*v_ld + c] - i.e. straight into svcat([x1, x2, x3, x4]) of sv_dgcnn_cls.py:68 (no concatenation pass).        */
@@ -256,7 +269,8 @@ int svnet_edgeblock_bwd_prelude_f32(const float* gs, const float* gv, const int3
 /* red / redv: the SVNET_RED_SLICES slices a prelude kernel filled (svnet_edgeblock_bwd_prelude_f32, svnet_xyzblock_bwd_prelude_f32). */
 int svnet_edgeblock_bwd_coeffs_f32(const float* red, const float* redv, const float* coef, const float* gamma1,
                                    const float* gamma2, int64_t E, int64_t Os, int64_t Ov, int training, const float* scale1,
-                                   float* bcoef, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, void* stream);
+                                   float* bcoef, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2,
+                                   const svnet_gate_bwd_job* gate_job /* may be NULL */, void* stream);
 int svnet_edgeblock_bwd_f32(const svnet_edgeblock_bwd_desc* desc, void* stream);
 /* Reverse neighbour lists of a kNN graph (idx [B*N,k], cloud-local ids): the edges e = i*k + t that point at j are
  * rev_edge[rev_range[2j] .. rev_range[2j+1]), their source points i (global ids) rev_src[..].  rev_range [2*B*N], rev_edge and
@@ -312,7 +326,7 @@ int svnet_xyzblock_coeffs_f32(const double* stat_y, const double* stat_v, int64_
                               const float* gamma1, const float* beta1, float* running_mean1, float* running_var1,
                               const float* gamma2, const float* beta2, float* running_mean2, float* running_var2,
                               int training, float eps, float momentum, float* coef, int64_t* num_batches_tracked1,
-                              int64_t* num_batches_tracked2, void* stream);
+                              int64_t* num_batches_tracked2, const svnet_gate_fwd_job* gate_job /* may be NULL */, void* stream);
 int svnet_xyzblock_apply_f32(const float* y_max, const float* y_min, const float* mv, const float* mvn, const float* coef,
                              const float* gate, int64_t P, int64_t N, int64_t Os, int64_t Ov, float slope, float* s_out,
                              float* v_out, float* s_cat, int64_t s_ld, float* v_cat, int64_t v_ld /* as svnet_edgeblock_apply_f32 */,

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVNET_DIAG_LIB") or os.path.join(_HERE, "libsvnet_hip.so")    # (SVNET_DIAG_LIB: an ablation build, tools/ only)
 _lib = None
-ABI_VERSION = 403       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
+ABI_VERSION = 404       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
 
 c_p = ctypes.c_void_p
 c_i64 = ctypes.c_int64
@@ -40,6 +40,18 @@ class GemmDesc(ctypes.Structure):
         ("workspace", c_p),
         ("workspace_bytes", ctypes.c_size_t),
     ]
+
+
+class GateFwdJob(ctypes.Structure):
+    """struct svnet_gate_fwd_job (include/svnet_hip.h): a gate MLP run beside a coefficient launch."""
+    _fields_ = [("gin", c_p), ("gin_f64", c_p), ("gin_out", c_p), ("in_scale", c_f), ("W0", c_p), ("W2", c_p),
+                ("B", c_i64), ("Cin", c_i64), ("H", c_i64), ("Ov", c_i64), ("h", c_p), ("gate", c_p)]
+
+
+class GateBwdJob(ctypes.Structure):
+    """struct svnet_gate_bwd_job (include/svnet_hip.h)."""
+    _fields_ = [("dgate", c_p), ("gate", c_p), ("h", c_p), ("gin", c_p), ("in_scale", c_f), ("W0", c_p), ("W2", c_p),
+                ("B", c_i64), ("Cin", c_i64), ("H", c_i64), ("Ov", c_i64), ("out_scale", c_f), ("dgin", c_p), ("dW0", c_p), ("dW2", c_p)]
 
 
 class EdgeBlockDesc(ctypes.Structure):
@@ -145,15 +157,15 @@ SIGNATURES = {
     "svnet_edgeblock_bwd_params_f32": (c_int, [c_p] * 8 + [c_i64] * 4 + [c_p] * 6 + [c_p]),
     "svnet_edgeblock_prepare_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p]),
     "svnet_edgeblock_fwd_f32": (c_int, [ctypes.POINTER(EdgeBlockDesc), c_p]),
-    "svnet_edgeblock_coeffs_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_f, c_f, c_p, c_p, c_p, c_p]),
+    "svnet_edgeblock_coeffs_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
     "svnet_edgeblock_apply_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p, c_i64, c_p, c_i64, c_p]),
     "svnet_edgeblock_wbt_bf16": (c_int, [c_p, c_p, c_i64, c_p, c_p]),
     "svnet_edgeblock_bwd_prelude_f32": (c_int, [c_p] * 9 + [c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_i64, c_p, c_p]),
-    "svnet_edgeblock_bwd_coeffs_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "svnet_edgeblock_bwd_coeffs_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "svnet_edgeblock_bwd_f32": (c_int, [ctypes.POINTER(EdgeBlockBwdDesc), c_p]),
     "svnet_edgeblock_wgrad_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, ctypes.c_uint32, c_p]),
     "svnet_xyzblock_fwd_f32": (c_int, [ctypes.POINTER(XyzBlockDesc), c_p]),
-    "svnet_xyzblock_coeffs_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_f, c_f, c_p, c_p, c_p, c_p]),
+    "svnet_xyzblock_coeffs_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
     "svnet_xyzblock_apply_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p, c_i64, c_p, c_i64, c_p]),
     "svnet_xyzblock_bwd_prelude_f32": (c_int, [c_p] * 8 + [c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_i64, c_p, c_p]),
     "svnet_xyzblock_bwd_f32": (c_int, [ctypes.POINTER(XyzBlockBwdDesc), c_p]),

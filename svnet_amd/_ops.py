@@ -1440,13 +1440,13 @@ class EdgeBlock(torch.autograd.Function):
         h = torch.empty((B, H), **f32)
         gate = torch.empty((B, Ov), **f32)
         gin = torch.empty((B, 2 * Cs), **f32)
-        call("svnet_gate_mlp_fwd_f32", None, _p(gate_sum), _p(gin), 1.0 / float(N * k), _p(Wg0c), _p(Wg2c), B, 2 * Cs, H, Ov, _p(h), _p(gate),
-             _stream())
-        _tap_act(Wg0, 2, h)
+        # (the MLP runs in extra workgroups of the coefficient launch below: the two only share their inputs)
+        job = _lib.GateFwdJob(None, _p(gate_sum), _p(gin), 1.0 / float(N * k), _p(Wg0c), _p(Wg2c), B, 2 * Cs, H, Ov, _p(h), _p(gate))
 
         coef = torch.empty((4 * Os + 4 * Ov,), **f32)
         call("svnet_edgeblock_coeffs_f32", _p(stat_n), _p(stat_v), E, Os, Ov, _p(sc1), _p(g1), _p(b1), _p(rm1), _p(rv1),
-             _p(g2), _p(b2), _p(rm2), _p(rv2), int(training), BN_EPS, BN_MOMENTUM, _p(coef), _p(nbt1), _p(nbt2), _stream())
+             _p(g2), _p(b2), _p(rm2), _p(rv2), int(training), BN_EPS, BN_MOMENTUM, _p(coef), _p(nbt1), _p(nbt2), ctypes.byref(job), _stream())
+        _tap_act(Wg0, 2, h)
         s_out = torch.empty((B, N, Os), **f32)
         v_out = torch.empty((B, N, 3, Ov), **f32)
         slot = _SINK.slot(B, N, Os, Ov, dev) if _SINK is not None else None
@@ -1516,15 +1516,14 @@ class EdgeBlock(torch.autograd.Function):
         bcoef = torch.empty((8 * Os + 2 * Ov + 4,), **f32)
         dg1, db1 = torch.empty((Os,), **f32), torch.empty((Os,), **f32)
         dg2, db2 = torch.empty((Ov,), **f32), torch.empty((Ov,), **f32)
-        call("svnet_edgeblock_bwd_coeffs_f32", _p(red), _p(redv), _p(coef), _p(g1), _p(g2), E, Os, Ov, int(training), _p(sc1), _p(bcoef),
-             _p(dg1), _p(db1), _p(dg2), _p(db2), _stream())
-        coeffs_done = main.record_event() if config.VEC_EARLY else None      # (what the vector path waits for: not the gate MLP's backward)
-
-        # ---- gate MLP backward: dW0, dW2 and the per-edge constant of the gate path, one workgroup per cloud
+        # ---- gate MLP backward (dW0, dW2 and the per-edge constant of the gate path, workgroups per cloud) in extra workgroups of the
+        # coefficient launch: both start from the prelude's sums only
         gconst = torch.empty((B, 2 * Cs), **f32)
         inv_nk = 1.0 / float(N * k)
-        call("svnet_gate_mlp_bwd_f32", _p(dgate), _p(gate), _p(h), _p(gin), inv_nk, _p(Wg0), _p(Wg2), B, 2 * Cs, H, Ov,
-             inv_nk, _p(gconst), _p(dWg0), _p(dWg2), _stream())
+        job = _lib.GateBwdJob(_p(dgate), _p(gate), _p(h), _p(gin), inv_nk, _p(Wg0), _p(Wg2), B, 2 * Cs, H, Ov, inv_nk, _p(gconst), _p(dWg0), _p(dWg2))
+        call("svnet_edgeblock_bwd_coeffs_f32", _p(red), _p(redv), _p(coef), _p(g1), _p(g2), E, Os, Ov, int(training), _p(sc1), _p(bcoef),
+             _p(dg1), _p(db1), _p(dg2), _p(db2), ctypes.byref(job), _stream())
+        coeffs_done = main.record_event() if config.VEC_EARLY else None      # (what the vector path waits for)
 
         # ---- the edge pass
         affine = k >= 8        # the weight-gradient GEMM recomputes dL/dy_pre from n16: the tile kernel then writes no fp32 [E,Os] tensor
@@ -1673,13 +1672,13 @@ class XyzBlock(torch.autograd.Function):
         h = torch.empty((B, H), **f32)
         gate = torch.empty((B, Ov), **f32)
         gin = torch.empty((B, NG), **f32)
-        call("svnet_gate_mlp_fwd_f32", None, _p(gate_sum), _p(gin), 1.0 / float(N * k), _p(_f32c(Wg0)), _p(_f32c(Wg2)), B, NG, H, Ov, _p(h),
-             _p(gate), _stream())
-        _tap_act(Wg0, 2, h)
+        Wg0c, Wg2c = _f32c(Wg0), _f32c(Wg2)
+        job = _lib.GateFwdJob(None, _p(gate_sum), _p(gin), 1.0 / float(N * k), _p(Wg0c), _p(Wg2c), B, NG, H, Ov, _p(h), _p(gate))   # (beside the coefficients)
 
         coef = torch.empty((4 * Os + 4 * Ov,), **f32)
         call("svnet_xyzblock_coeffs_f32", _p(stat_y), _p(stat_v), E, Os, Ov, _p(g1), _p(b1), _p(rm1), _p(rv1), _p(g2), _p(b2), _p(rm2),
-             _p(rv2), int(training), BN_EPS, BN_MOMENTUM, _p(coef), _p(nbt1), _p(nbt2), _stream())
+             _p(rv2), int(training), BN_EPS, BN_MOMENTUM, _p(coef), _p(nbt1), _p(nbt2), ctypes.byref(job), _stream())
+        _tap_act(Wg0, 2, h)
         s_out = torch.empty((B, N, Os), **f32)
         v_out = torch.empty((B, N, 3, Ov), **f32)
         slot = _SINK.slot(B, N, Os, Ov, dev) if _SINK is not None else None
@@ -1722,13 +1721,13 @@ class XyzBlock(torch.autograd.Function):
         bcoef = torch.empty((3 * Os + 2 * Ov,), **f32)
         dg1, db1 = torch.empty((Os,), **f32), torch.empty((Os,), **f32)
         dg2, db2 = torch.empty((Ov,), **f32), torch.empty((Ov,), **f32)
-        call("svnet_edgeblock_bwd_coeffs_f32", _p(red), _p(redv), _p(coef), _p(g1), _p(g2), E, Os, Ov, int(training), None, _p(bcoef),
-             _p(dg1), _p(db1), _p(dg2), _p(db2), _stream())
-        # gate MLP backward
+        # gate MLP backward, in extra workgroups of the coefficient launch
         gconst = torch.empty((B, NG), **f32)
         inv_nk = 1.0 / float(N * k)
-        call("svnet_gate_mlp_bwd_f32", _p(dgate), _p(gate), _p(h), _p(gin), inv_nk, _p(_f32c(Wg0)), _p(_f32c(Wg2)), B, NG, H, Ov, inv_nk,
-             _p(gconst), _p(dWg0), _p(dWg2), _stream())
+        Wg0c, Wg2c = _f32c(Wg0), _f32c(Wg2)
+        job = _lib.GateBwdJob(_p(dgate), _p(gate), _p(h), _p(gin), inv_nk, _p(Wg0c), _p(Wg2c), B, NG, H, Ov, inv_nk, _p(gconst), _p(dWg0), _p(dWg2))
+        call("svnet_edgeblock_bwd_coeffs_f32", _p(red), _p(redv), _p(coef), _p(g1), _p(g2), E, Os, Ov, int(training), None, _p(bcoef),
+             _p(dg1), _p(db1), _p(dg2), _p(db2), ctypes.byref(job), _stream())
         # edge pass: parameter gradients
         d = XyzBlockBwdDesc()
         d.B, d.N, d.k, d.Os, d.Ov = B, N, k, Os, Ov
@@ -1756,7 +1755,7 @@ def _side_stream(dev):
     key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
     if key not in _SIDE_STREAMS:
         # (a high-priority side stream was measured: 10.7 ms per step against 6.4 - the tile kernel on the main stream starves)
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key, priority=config.SIDE_PRIORITY)
     return _SIDE_STREAMS[key]
 
 

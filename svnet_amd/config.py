@@ -46,3 +46,9 @@ VEC_EARLY = True
 GATE_ON_SIDE = False     # measured: 4.57 - 4.60 ms with the gate on the main stream, 4.62 on the side (the vector path is then the longer one)
 # sign-weight products with many rows and more than 128 columns go to the LDS-tiled rows kernel from this K on (it needs K >= 64)
 ROWS2_MIN_K = 64
+
+# Stream priorities (torch: lower number = higher priority; -1 is the highest this build hands out, 0 the default).  MAIN_PRIORITY is the
+# priority of the stream a step is captured on (svnet_amd.train), SIDE_PRIORITY that of the side stream (_ops._side_stream: the vector
+# path of an SVBlock on rows and the deferred weight-gradient chains).
+MAIN_PRIORITY = 0
+SIDE_PRIORITY = 0

@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "gate_mlp.h"
 
 namespace {
 
@@ -608,7 +609,9 @@ __global__ void edgeblock_coeffs_kernel(const long long* __restrict__ stat_n, co
                                         const float* __restrict__ b1, float* __restrict__ rm1, float* __restrict__ rv1,
                                         const float* __restrict__ g2, const float* __restrict__ b2, float* __restrict__ rm2,
                                         float* __restrict__ rv2, int training, float eps, float momentum,
-                                        float* __restrict__ coef, long long* __restrict__ nbt1, long long* __restrict__ nbt2) {
+                                        float* __restrict__ coef, long long* __restrict__ nbt1, long long* __restrict__ nbt2,
+                                        svnet_gate_fwd_job job, int coef_blocks) {
+    if ((int)blockIdx.x >= coef_blocks) { svnet_gate_fwd_block(job, (int)blockIdx.x - coef_blocks); return; }   // the gate MLP beside the coefficients
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && training) {
         if (nbt1) *nbt1 += 1;
@@ -753,15 +756,18 @@ extern "C" int svnet_edgeblock_coeffs_f32(const int64_t* stat_n, const double* s
                                           const float* scale1, const float* gamma1, const float* beta1, float* running_mean1,
                                           float* running_var1, const float* gamma2, const float* beta2, float* running_mean2,
                                           float* running_var2, int training, float eps, float momentum, float* coef,
-                                          int64_t* num_batches_tracked1, int64_t* num_batches_tracked2, void* stream) {
+                                          int64_t* num_batches_tracked1, int64_t* num_batches_tracked2, const svnet_gate_fwd_job* gate_job, void* stream) {
     SVNET_REQUIRE(scale1 && gamma1 && beta1 && gamma2 && beta2 && coef && E > 0 && Os > 0 && Ov > 0, SVNET_E_ARG, "svnet_edgeblock_coeffs_f32: bad arguments");
     SVNET_REQUIRE(training ? (stat_n && stat_v) : (running_mean1 && running_var1 && running_mean2 && running_var2), SVNET_E_ARG,
                   "svnet_edgeblock_coeffs_f32: missing statistics");
     const int64_t n = Os > Ov ? Os : Ov;
-    hipLaunchKernelGGL(edgeblock_coeffs_kernel, dim3((unsigned)svnet_cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream,
+    SVNET_REQUIRE(!gate_job || svnet_gate_fwd_job_ok(gate_job), SVNET_E_ARG, "svnet_edgeblock_coeffs_f32: bad gate job");
+    const int coef_blocks = (int)svnet_cdiv(n, 256);
+    const svnet_gate_fwd_job job = gate_job ? *gate_job : svnet_gate_fwd_job{};
+    hipLaunchKernelGGL(edgeblock_coeffs_kernel, dim3((unsigned)(coef_blocks + (gate_job ? gate_job->B : 0))), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const long long*>(stat_n), stat_v, E, (int)Os, (int)Ov, scale1, gamma1, beta1, running_mean1,
                        running_var1, gamma2, beta2, running_mean2, running_var2, training, eps, momentum, coef,
-                       reinterpret_cast<long long*>(num_batches_tracked1), reinterpret_cast<long long*>(num_batches_tracked2));
+                       reinterpret_cast<long long*>(num_batches_tracked1), reinterpret_cast<long long*>(num_batches_tracked2), job, coef_blocks);
     SVNET_CHECK_LAUNCH("edgeblock_coeffs_kernel");
     return SVNET_OK;
 }

@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "gate_mlp.h"
 #include "prelude.h"
 
 namespace {
@@ -192,7 +193,12 @@ __global__ void edgeblock_bwd_coeffs_kernel(const float* __restrict__ red, const
                                             const float* __restrict__ g1, const float* __restrict__ g2, int64_t E, int Os, int Ov,
                                             int training, const float* __restrict__ scale1, float* __restrict__ bcoef,
                                             float* __restrict__ dg1, float* __restrict__ db1, float* __restrict__ dg2,
-                                            float* __restrict__ db2) {
+                                            float* __restrict__ db2, svnet_gate_bwd_job job, int coef_blocks, int gate_chunks) {
+    if ((int)blockIdx.x >= coef_blocks) {                              // the gate MLP's backward beside the coefficients
+        const int g = (int)blockIdx.x - coef_blocks;
+        svnet_gate_bwd_block(job, g / gate_chunks, g % gate_chunks, gate_chunks);
+        return;
+    }
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const float invE = 1.f / (float)E;
     if (c < Os) {
@@ -1092,12 +1098,18 @@ extern "C" int svnet_edgeblock_bwd_prelude_f32(const float* gs, const float* gv,
 
 extern "C" int svnet_edgeblock_bwd_coeffs_f32(const float* red, const float* redv, const float* coef, const float* gamma1,
                                               const float* gamma2, int64_t E, int64_t Os, int64_t Ov, int training, const float* scale1,
-                                              float* bcoef, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, void* stream) {
+                                              float* bcoef, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2,
+                                              const svnet_gate_bwd_job* gate_job, void* stream) {
     SVNET_REQUIRE(red && redv && coef && gamma1 && gamma2 && bcoef && dgamma1 && dbeta1 && dgamma2 && dbeta2 && E > 0, SVNET_E_ARG,
                   "svnet_edgeblock_bwd_coeffs_f32: bad arguments");
     const int64_t n = Os > Ov ? Os : Ov;
-    hipLaunchKernelGGL(edgeblock_bwd_coeffs_kernel, dim3((unsigned)svnet_cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream, red, redv, coef,
-                       gamma1, gamma2, E, (int)Os, (int)Ov, training, scale1, bcoef, dgamma1, dbeta1, dgamma2, dbeta2);
+    SVNET_REQUIRE(!gate_job || svnet_gate_bwd_job_ok(gate_job), SVNET_E_ARG, "svnet_edgeblock_bwd_coeffs_f32: bad gate job");
+    const int coef_blocks = (int)svnet_cdiv(n, 256);
+    const svnet_gate_bwd_job job = gate_job ? *gate_job : svnet_gate_bwd_job{};
+    const int chunks = gate_job ? svnet_gate_bwd_chunks(job.Cin, job.H, job.Ov) : 1;
+    hipLaunchKernelGGL(edgeblock_bwd_coeffs_kernel, dim3((unsigned)(coef_blocks + (gate_job ? gate_job->B * chunks : 0))), dim3(256), 0,
+                       (hipStream_t)stream, red, redv, coef, gamma1, gamma2, E, (int)Os, (int)Ov, training, scale1, bcoef, dgamma1, dbeta1,
+                       dgamma2, dbeta2, job, coef_blocks, chunks);
     SVNET_CHECK_LAUNCH("edgeblock_bwd_coeffs_kernel");
     return SVNET_OK;
 }

@@ -9,6 +9,7 @@
 #include <float.h>
 
 #include "common.h"
+#include "gate_mlp.h"
 
 namespace {
 
@@ -658,74 +659,8 @@ extern "C" int svnet_smooth_ce_f32(const float* logits, const int64_t* target, i
 // whole chain rule (backward) instead of 4 + 8 launch-bound micro-kernels.
 namespace {
 
-__global__ __launch_bounds__(256) void gate_mlp_fwd_kernel(const float* __restrict__ gin, const double* __restrict__ gin_f64,
-                                                           float* __restrict__ gin_out, float in_scale, const float* __restrict__ W0,
-                                                           const float* __restrict__ W2, int Cin, int H, int Ov,
-                                                           float* __restrict__ h, float* __restrict__ gate) {
-    __shared__ float hs[256];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    if (gin_f64) {   // fp64 sums of a fused edge layer: rounded to fp32 once, kept (gin_out) for the backward
-        for (int c = tid; c < Cin; c += blockDim.x) gin_out[(size_t)b * Cin + c] = (float)gin_f64[(size_t)b * Cin + c];
-        __syncthreads();
-        gin = gin_out;
-    }
-    const float* g = gin + (size_t)b * Cin;
-    for (int j = tid; j < H; j += blockDim.x) {
-        float a = 0.f;
-#pragma unroll 8
-        for (int c = 0; c < Cin; ++c) a = fmaf(g[c] * in_scale, W0[j * Cin + c], a);
-        a = a > 0.f ? a : 0.f;
-        hs[j] = a;
-        h[(size_t)b * H + j] = a;
-    }
-    __syncthreads();
-    for (int o = tid; o < Ov; o += blockDim.x) {
-        float a = 0.f;
-        for (int j = 0; j < H; ++j) a = fmaf(hs[j], W2[o * H + j], a);
-        gate[(size_t)b * Ov + o] = 1.f / (1.f + expf(-a));
-    }
-}
-
-// dgin[b,c] = out_scale * sum_j dhpre[b,j] W0[j,c];  dW0 += dhpre^T (in_scale*gin);  dW2 += dgpre^T h   (atomics, zero-filled)
-__global__ __launch_bounds__(256) void gate_mlp_bwd_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
-                                                           const float* __restrict__ h, const float* __restrict__ gin, float in_scale,
-                                                           const float* __restrict__ W0, const float* __restrict__ W2, int Cin, int H,
-                                                           int Ov, float out_scale, float* __restrict__ dgin, float* __restrict__ dW0,
-                                                           float* __restrict__ dW2) {
-    // grid (B, chunks): every workgroup recomputes the two short per-cloud vectors (cheap) and takes every chunks-th slice of
-    // the three output loops, so that a wide layer (conv5: 85 x 256 + 170 x 85 outputs) is not 32 long serial loops
-    __shared__ float dgp[256], dhp[256];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int t0 = blockIdx.y * blockDim.x + tid, ts = gridDim.y * blockDim.x;
-    for (int o = tid; o < Ov; o += blockDim.x) {
-        const float gt = gate[(size_t)b * Ov + o];
-        dgp[o] = dgate[(size_t)b * Ov + o] * gt * (1.f - gt);
-    }
-    __syncthreads();
-    for (int j = tid; j < H; j += blockDim.x) {
-        float a = 0.f;
-#pragma unroll 8
-        for (int o = 0; o < Ov; ++o) a = fmaf(dgp[o], W2[o * H + j], a);
-        dhp[j] = h[(size_t)b * H + j] > 0.f ? a : 0.f;
-    }
-    __syncthreads();
-    for (int e = t0; e < Ov * H; e += ts) {
-        const int o = e / H, j = e - o * H;
-        atomicAdd(&dW2[e], dgp[o] * h[(size_t)b * H + j]);
-    }
-    for (int e = t0; e < H * Cin; e += ts) {
-        const int j = e / Cin, c = e - j * Cin;
-        atomicAdd(&dW0[e], dhp[j] * gin[(size_t)b * Cin + c] * in_scale);
-    }
-    if (dgin) {
-        for (int c = t0; c < Cin; c += ts) {
-            float a = 0.f;
-#pragma unroll 8
-            for (int j = 0; j < H; ++j) a = fmaf(dhp[j], W0[j * Cin + c], a);
-            dgin[(size_t)b * Cin + c] = a * out_scale;
-        }
-    }
-}
+__global__ __launch_bounds__(256) void gate_mlp_fwd_kernel(svnet_gate_fwd_job j) { svnet_gate_fwd_block(j, blockIdx.x); }
+__global__ __launch_bounds__(256) void gate_mlp_bwd_kernel(svnet_gate_bwd_job j) { svnet_gate_bwd_block(j, blockIdx.x, blockIdx.y, gridDim.y); }
 
 }  // namespace
 
@@ -736,8 +671,8 @@ extern "C" int svnet_gate_mlp_fwd_f32(const float* gin, const double* gin_f64, f
                   "svnet_gate_mlp_fwd_f32: bad arguments");
     SVNET_REQUIRE(H <= 256 && Ov <= 256, SVNET_E_UNSUPPORTED, "svnet_gate_mlp_fwd_f32: H, Ov must be <= 256");
     if (B == 0) return SVNET_OK;
-    hipLaunchKernelGGL(gate_mlp_fwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, gin, gin_f64, gin_out, in_scale, W0, W2,
-                       (int)Cin, (int)H, (int)Ov, h, gate);
+    const svnet_gate_fwd_job j = {gin, gin_f64, gin_out, in_scale, W0, W2, B, Cin, H, Ov, h, gate};
+    hipLaunchKernelGGL(gate_mlp_fwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, j);
     SVNET_CHECK_LAUNCH("gate_mlp_fwd_kernel");
     return SVNET_OK;
 }
@@ -749,11 +684,9 @@ extern "C" int svnet_gate_mlp_bwd_f32(const float* dgate, const float* gate, con
                   "svnet_gate_mlp_bwd_f32: bad arguments");
     SVNET_REQUIRE(H <= 256 && Ov <= 256, SVNET_E_UNSUPPORTED, "svnet_gate_mlp_bwd_f32: H, Ov must be <= 256");
     if (B == 0) return SVNET_OK;
-    int64_t chunks = svnet_cdiv(H * Cin + Ov * H, 256 * 8);          // ~8 outputs per thread
-    if (chunks > 16) chunks = 16;
-    if (chunks < 1) chunks = 1;
-    hipLaunchKernelGGL(gate_mlp_bwd_kernel, dim3((unsigned)B, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, dgate, gate, h, gin,
-                       in_scale, W0, W2, (int)Cin, (int)H, (int)Ov, out_scale, dgin, dW0, dW2);
+    const int chunks = svnet_gate_bwd_chunks(Cin, H, Ov);
+    const svnet_gate_bwd_job j = {dgate, gate, h, gin, in_scale, W0, W2, B, Cin, H, Ov, out_scale, dgin, dW0, dW2};
+    hipLaunchKernelGGL(gate_mlp_bwd_kernel, dim3((unsigned)B, (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, j);
     SVNET_CHECK_LAUNCH("gate_mlp_bwd_kernel");
     return SVNET_OK;
 }

@@ -16,6 +16,7 @@
 
 #include "common.h"
 #include "prelude.h"
+#include "gate_mlp.h"
 
 namespace {
 
@@ -264,7 +265,9 @@ __global__ void xyzblock_coeffs_kernel(const double* __restrict__ stat_y, const 
                                        const float* __restrict__ g1, const float* __restrict__ b1, float* __restrict__ rm1,
                                        float* __restrict__ rv1, const float* __restrict__ g2, const float* __restrict__ b2,
                                        float* __restrict__ rm2, float* __restrict__ rv2, int training, float eps, float momentum,
-                                       float* __restrict__ coef, long long* __restrict__ nbt1, long long* __restrict__ nbt2) {
+                                       float* __restrict__ coef, long long* __restrict__ nbt1, long long* __restrict__ nbt2,
+                                       svnet_gate_fwd_job job, int coef_blocks) {
+    if ((int)blockIdx.x >= coef_blocks) { svnet_gate_fwd_block(job, (int)blockIdx.x - coef_blocks); return; }   // the gate MLP beside the coefficients
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && training) {
         if (nbt1) *nbt1 += 1;
@@ -612,15 +615,18 @@ extern "C" int svnet_xyzblock_coeffs_f32(const double* stat_y, const double* sta
                                          const float* gamma1, const float* beta1, float* running_mean1, float* running_var1,
                                          const float* gamma2, const float* beta2, float* running_mean2, float* running_var2,
                                          int training, float eps, float momentum, float* coef, int64_t* num_batches_tracked1,
-                                         int64_t* num_batches_tracked2, void* stream) {
+                                         int64_t* num_batches_tracked2, const svnet_gate_fwd_job* gate_job, void* stream) {
     SVNET_REQUIRE(gamma1 && beta1 && gamma2 && beta2 && coef && E > 0 && Os > 0 && Ov > 0, SVNET_E_ARG, "svnet_xyzblock_coeffs_f32: bad arguments");
     SVNET_REQUIRE(training ? (stat_y && stat_v) : (running_mean1 && running_var1 && running_mean2 && running_var2), SVNET_E_ARG,
                   "svnet_xyzblock_coeffs_f32: missing statistics");
     const int64_t n = Os > Ov ? Os : Ov;
-    hipLaunchKernelGGL(xyzblock_coeffs_kernel, dim3((unsigned)svnet_cdiv(n, 128)), dim3(128), 0, (hipStream_t)stream, stat_y, stat_v, E,
+    SVNET_REQUIRE(!gate_job || svnet_gate_fwd_job_ok(gate_job), SVNET_E_ARG, "svnet_xyzblock_coeffs_f32: bad gate job");
+    const int coef_blocks = (int)svnet_cdiv(n, 256);
+    const svnet_gate_fwd_job job = gate_job ? *gate_job : svnet_gate_fwd_job{};
+    hipLaunchKernelGGL(xyzblock_coeffs_kernel, dim3((unsigned)(coef_blocks + (gate_job ? gate_job->B : 0))), dim3(256), 0, (hipStream_t)stream, stat_y, stat_v, E,
                        (int)Os, (int)Ov, gamma1, beta1, running_mean1, running_var1, gamma2, beta2, running_mean2, running_var2,
                        training, eps, momentum, coef, reinterpret_cast<long long*>(num_batches_tracked1),
-                       reinterpret_cast<long long*>(num_batches_tracked2));
+                       reinterpret_cast<long long*>(num_batches_tracked2), job, coef_blocks);
     SVNET_CHECK_LAUNCH("xyzblock_coeffs_kernel");
     return SVNET_OK;
 }

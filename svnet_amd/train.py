@@ -84,7 +84,7 @@ class TrainStep:
         whose autograd graph is still alive (AccumulateGrad nodes) would fork the capture onto that stream.
         `before_capture`: called between the warm-up and the capture (diagnostics: tools/step_clock.py arms its stamps there)."""
         dev = self.bucket.flat.device
-        self._stream = torch.cuda.Stream(device=dev)
+        self._stream = torch.cuda.Stream(device=dev, priority=config.MAIN_PRIORITY)
         self._stream.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(self._stream):
             for _ in range(warmup):
@@ -135,7 +135,7 @@ class ForwardStep:
 
     def capture(self, warmup=2):
         dev = self.inputs[0].device
-        stream = torch.cuda.Stream(device=dev)
+        stream = torch.cuda.Stream(device=dev, priority=config.MAIN_PRIORITY)
         stream.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(stream):
             for _ in range(warmup):
