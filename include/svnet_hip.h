@@ -47,7 +47,7 @@ int svnet_slices_sum_f64(double* buf, int64_t L, void* stream);
  * changes its required length (200: sliced accumulators, SVNET_SLICED_LEN; 400: this header; 401: the totals of a sliced accumulator are
  * written by its consumer, svnet_slices_sum_*; 402: GX of svnet_v2s_bwd_*, gw of svnet_xyzblock_bwd_f32 and col_sum of svnet_gemm_f32 are sliced accumulators; 403: svnet_binweight_grad_f32 takes sliced inputs).  svnet_version() returns the value the
  * library was BUILT with: a caller compiled against another header must refuse to run (svnet_amd/_lib.py does).                   */
-#define SVNET_ABI_VERSION 404
+#define SVNET_ABI_VERSION 405
 int svnet_version(void);
 const char* svnet_last_error(void);
 
@@ -390,6 +390,12 @@ int svnet_vproject_bwd_f32(const float* v, const float* z, const float* ds, int6
  * zero-filled by the caller).
  * kind 0: x is [M,C];  kind 1: x is [M,3,C] and the statistic is n = ||x[m,:,c]||_2 + 1e-6 (VectorBN, :94). */
 int svnet_colstats_f64(const float* x, int64_t M, int64_t C, int kind, double* sums, void* stream);
+/* The vector path's linear layer of an SVBlock on rows together with the batch statistics of the VectorBN behind it
+ * (sv_layers.py:44-49 with bw only, :86-102, :192): v [P,3,K] rows, w_b [O,K] the +-1 / 0 values of sign(W), col_scale [O] (may be NULL);
+ * y[p,a,o] = col_scale[o] * sum_k v[p,a,k] w_b[o,k];  `sums` as svnet_colstats_f64 kind 1 leaves it for y (a sliced accumulator of
+ * 2*O doubles, zero-filled by the caller): the separate statistics pass over y is not needed.  K <= 96, O <= 256.                   */
+int svnet_vlinear_stats_f32(const float* v, int64_t P, int64_t K, const float* w_b, const float* col_scale, int64_t O, float* y,
+                            double* sums, void* stream);
 /* mean/invstd from the sums (training: `sums` = the sliced accumulator svnet_colstats_f64 / svnet_binlinear_i8_fwd_f32 filled; its totals
  * are left in sums[0:2C]), running-stat update and num_batches_tracked += 1 (each may be NULL). */
 int svnet_bn_finalize_f32(double* sums, int64_t M, int64_t C, float eps, float momentum, float* mean,

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVNET_DIAG_LIB") or os.path.join(_HERE, "libsvnet_hip.so")    # (SVNET_DIAG_LIB: an ablation build, tools/ only)
 _lib = None
-ABI_VERSION = 404       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
+ABI_VERSION = 405       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
 
 c_p = ctypes.c_void_p
 c_i64 = ctypes.c_int64
@@ -198,6 +198,7 @@ SIGNATURES = {
     "svnet_pool_maxmean_bwd_f32": (c_int, [c_p, c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p]),
     "svnet_act_fwd_f32": (c_int, [c_p, c_i64, c_int, c_p, c_p]),
     "svnet_act_bwd_f32": (c_int, [c_p, c_p, c_i64, c_int, c_p, c_p]),
+    "svnet_vlinear_stats_f32": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_p, c_p]),
     "svnet_gate_mlp_fwd_f32": (c_int, [c_p, c_p, c_p, c_f, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "svnet_gate_mlp_bwd_f32": (c_int, [c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p, c_p]),
     "svnet_adam_step_f32": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_p]),

@@ -407,7 +407,8 @@ def begin_step(dev, planes_external=False, arena=None):
 
 
 def end_step():
-    global ARENA, _FUSED_COLSUMS
+    global ARENA, _FUSED_COLSUMS, _FUSED_VSTATS
+    _FUSED_VSTATS = None
     _FUSED_COLSUMS = None                                 # (the producer's [M, O] output and its arena slice are not held across steps)
     ARENA.end()
     ARENA = _DEFAULT_ARENA
@@ -472,7 +473,10 @@ class BwLinear(torch.autograd.Function):
     """y = (x sign(W)^T) * scale with fp32 activations (sv_layers.py:44-49 with bw only: linear2, v2s.linear, svfuse)."""
 
     @staticmethod
-    def forward(ctx, x, W, scale, training=True):
+    def forward(ctx, x, W, scale, training=True, vstats=False):
+        """vstats: x is [..., 3, K] vectors and a VectorBN in training mode consumes the output next (SVBlock's linear2): the product
+        also leaves the VectorBN's batch sums (csrc/vlinear.hip) in _FUSED_VSTATS, where VBN.forward finds them - no statistics pass."""
+        global _FUSED_VSTATS
         _hip(x, W, scale)
         ctx.training = bool(training)
         x2 = _f32c(x).reshape(-1, x.shape[-1])
@@ -482,7 +486,14 @@ class BwLinear(torch.autograd.Function):
         sc = _f32c(scale).view(-1)
         w_b = _binweight(W_in, scale)["w_b"]
         y = torch.empty((M, O), dtype=torch.float32, device=x.device)
-        gemm(M, O, K, A=x2, a_rs=K, a_cs=1, B=w_b, b_rs=1, b_cs=K, b_exact=True, C=y, ldc=O, col_scale=sc)
+        _FUSED_VSTATS = None
+        if (vstats and training and config.FUSE_VBN_STATS and x.dim() >= 2 and x.shape[-2] == 3 and M % 3 == 0 and M > 0
+                and K <= 96 and O <= 256):
+            sums = _zeros((_sliced_len(2 * O),), torch.float64, x.device)
+            call("svnet_vlinear_stats_f32", _p(x2), M // 3, K, _p(w_b), _p(sc), O, _p(y), _p(sums), _stream())
+            _FUSED_VSTATS = (y, y._version, sums)
+        else:
+            gemm(M, O, K, A=x2, a_rs=K, a_cs=1, B=w_b, b_rs=1, b_cs=K, b_exact=True, C=y, ldc=O, col_scale=sc)
         ctx.save_for_backward(x2, W, sc, w_b)
         ctx.xshape, ctx.sshape = x.shape, scale.shape
         return y.view(x.shape[:-1] + (O,))
@@ -509,7 +520,7 @@ class BwLinear(torch.autograd.Function):
             gemm(M, K, O, A=g2, a_rs=O, a_cs=1, a_scale=sc, B=w_b, b_rs=K, b_cs=1, b_exact=True, C=dx, ldc=K)
             dx = dx.view(ctx.xshape)
         beside.join(dW, dsc)
-        return dx, dW, dsc, None
+        return dx, dW, dsc, None, None
 
 
 class BinLinear(torch.autograd.Function):
@@ -828,6 +839,7 @@ class VProject(torch.autograd.Function):
 # Column sums a producer left for the BatchNorm over its output: (the [M, C] tensor itself - held, so that its memory cannot be handed to
 # another tensor while the record lives -, its version at the time, sums [2C] double).  Consumed once; any later producer replaces it.
 _FUSED_COLSUMS = None
+_FUSED_VSTATS = None          # (y, version, sums) of the last BwLinear(vstats=True): the VectorBN sums of ITS output
 
 
 def _batch_stats(x, M, C, kind, running_mean, running_var, training, momentum, eps, nbt=None):
@@ -905,10 +917,16 @@ class VBN(torch.autograd.Function):
         M, _, C = v3.shape
         gate2 = None if gate is None else _f32c(gate).reshape(-1, C)
         out = torch.empty_like(v3)
+        global _FUSED_VSTATS
+        rec, _FUSED_VSTATS = _FUSED_VSTATS, None
         if training and M > 0:
             # statistics pass, then ONE kernel that finalises them per thread and applies them (no one-workgroup launch in between)
-            sums = _zeros((_sliced_len(2 * C),), torch.float64, v3.device)
-            call("svnet_colstats_f64", _p(v3), M, C, 1, _p(sums), _stream())
+            if (rec is not None and rec[0].data_ptr() == v3.data_ptr() and rec[0].numel() == v3.numel() and rec[0]._version == rec[1]
+                    and tuple(rec[0].shape) == (3 * M, C)):
+                sums = rec[2]                                   # the producing product's sums (csrc/vlinear.hip)
+            else:
+                sums = _zeros((_sliced_len(2 * C),), torch.float64, v3.device)
+                call("svnet_colstats_f64", _p(v3), M, C, 1, _p(sums), _stream())
             mean = torch.empty((C,), dtype=torch.float32, device=v3.device)
             invstd = torch.empty((C,), dtype=torch.float32, device=v3.device)
             call("svnet_vbn_fwd_stats_f32", _p(v3), _p(sums), eps, momentum, _p(mean), _p(invstd), _p(running_mean), _p(running_var), _p(nbt),

@@ -52,3 +52,10 @@ ROWS2_MIN_K = 64
 # path of an SVBlock on rows and the deferred weight-gradient chains).
 MAIN_PRIORITY = 0
 SIDE_PRIORITY = 0
+
+# SVBlock on rows: linear2's product also forms the batch sums of the VectorBN behind it (csrc/vlinear.hip; K <= 96, O <= 256) - no
+# statistics pass over its output.  Measured at conv5 of the classifier (32 768 points, 83 -> 170): alone 51 us + 57 us for the apply
+# pass (which then reads the product cold) against 72 + 21 + 44 for rows GEMM + statistics + apply, but IN the step 4.44 ms against 4.40
+# (two alternating runs: one 8-wave workgroup per CU holding 100 KB of LDS shares the CUs worse with the scalar path beside it than the
+# three lighter kernels did), and nothing on sv_pointnet_cls (5.61 against 5.62): off.
+FUSE_VBN_STATS = False

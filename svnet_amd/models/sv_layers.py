@@ -75,11 +75,12 @@ class Linear(nn.Linear):
         if bw:
             self.scale = nn.Parameter(torch.ones(1, out_channels) / math.sqrt(in_channels))
 
-    def forward(self, x):
+    def forward(self, x, vstats=False):
+        """vstats: a hint from SVBlock - x holds [..., 3, K] vectors and a VectorBN takes the output next (see _ops.BwLinear)."""
         if self.bw and self.ba:
             return _ops.BinLinear.apply(x, self.weight, self.beta, self.scale, self.bias, self.training)
         if self.bw:
-            y = _ops.BwLinear.apply(x, self.weight, self.scale, self.training)
+            y = _ops.BwLinear.apply(x, self.weight, self.scale, self.training, bool(vstats) and self.bias is None)
             return y if self.bias is None else y + self.bias
         if self.ba:
             raise AttributeError("'Linear' object has no attribute 'scale'")  # same failure as the reference (:49)
@@ -367,7 +368,7 @@ class SVBlock(nn.Module):
             main, side = torch.cuda.current_stream(s.device), _ops._side_stream(s.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                v_lin = self.linear2(v)
+                v_lin = self.linear2(v, vstats=True)
             fused = self._cat_and_gate(s, v, side if config.GATE_ON_SIDE else None)
             if fused is not None:
                 s_cat, v_scale = fused
@@ -389,7 +390,7 @@ class SVBlock(nn.Module):
         if not prebn:
             s = batch_norm_act(self.bn1, s, _ACT_LEAKY, self.relu.negative_slope)
 
-        v = self.linear2(v)
+        v = self.linear2(v, vstats=True)
         v = self.bn2(v, gate=v_scale)
         return (s, v)
 

@@ -310,3 +310,57 @@ def test_sliced_sums_are_complete_every_time(hip_device):
         for i, (got, ref) in enumerate(((sv[:2 * C], ref_v), (sx[:1024], ref_x), (red[:1024].double(), ref_r))):
             worst[i] = max(worst[i], float((got - ref).abs().max() / ref.abs().max()))
     assert worst[0] < 1e-6 and worst[1] < 1e-6 and worst[2] < 1e-4, worst
+
+
+# ----------------------------------------------------------------------------- linear2 + VectorBN statistics in one product (csrc/vlinear.hip)
+
+@pytest.mark.parametrize("P,K,O,gated", [(1000, 10, 10, False), (4096, 21, 170, True), (2500, 83, 170, True), (777, 96, 256, False),
+                                         (64, 20, 21, True), (33, 3, 5, False)])
+def test_linear2_with_vectorbn_sums_matches_the_two_pass_chain(P, K, O, gated, hip_device):
+    """SVBlock's vector path on rows, sv_layers.py:192-194: v' = bn2(linear2(v)) * gate.  The product that also forms the VectorBN's
+    batch sums (n = ||y[p,:,o]|| + 1e-6: sum n, sum n^2) must give the layer-wise chain's numbers - rows GEMM, svnet_colstats_f64
+    kind 1, apply - forward and backward, including a last tile of fewer than 32 points and column tiles past O."""
+    from svnet_amd import _ops, config
+    from svnet_amd.models.sv_layers import Linear, VectorBN
+    torch.manual_seed(P + K + O)
+    B = 1 if P % 8 else 8
+    with contextlib.redirect_stdout(io.StringIO()):
+        lin = Linear(K, O, bias=False, bw=True).to(hip_device).train()
+        bn = VectorBN(O).to(hip_device).train()
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(O, K)); lin.weight[:, :1].zero_()              # a sign(0) = 0 column
+        bn.bn.weight.copy_(torch.rand(O) + 0.5); bn.bn.bias.copy_(torch.randn(O) * 0.1)
+    v = torch.randn(B, P // B, 3, K, device=hip_device) * 1.7
+    gate = torch.rand(B, O, device=hip_device) if gated else None
+    g = torch.randn(B, P // B, 3, O, device=hip_device)
+    outs, default = {}, config.FUSE_VBN_STATS
+    for fused in (False, True):
+        config.FUSE_VBN_STATS = fused
+        try:
+            bn.bn.running_mean.zero_(); bn.bn.running_var.fill_(1.0); bn.bn.num_batches_tracked.zero_()
+            vv = v.clone().requires_grad_(True)
+            for p_ in list(lin.parameters()) + list(bn.parameters()):
+                p_.grad = None
+            calls = []
+            real = _ops.call
+            _ops.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+            try:
+                out = bn(lin(vv, vstats=True), gate=gate)
+            finally:
+                _ops.call = real
+            out.backward(g)
+            torch.cuda.synchronize()
+            outs[fused] = dict(out=out.detach().clone(), dv=vv.grad.clone(), dW=lin.weight.grad.clone(), dsc=lin.scale.grad.clone(),
+                               dg=bn.bn.weight.grad.clone(), db=bn.bn.bias.grad.clone(), rm=bn.bn.running_mean.clone(),
+                               rv=bn.bn.running_var.clone(), calls=calls)
+        finally:
+            config.FUSE_VBN_STATS = default
+    assert "svnet_vlinear_stats_f32" in outs[True]["calls"] and "svnet_colstats_f64" not in outs[True]["calls"]
+    assert "svnet_colstats_f64" in outs[False]["calls"] and "svnet_vlinear_stats_f32" not in outs[False]["calls"]
+    for key in ("out", "dv", "dW", "dsc", "dg", "db", "rm", "rv"):
+        a, b = outs[True][key], outs[False][key]
+        ref = b.abs().max().clamp_min(1e-30)
+        if key == "dsc":      # VectorBN normalises the length: the output does not depend on linear2's scale, its gradient is the rounding
+            ref = outs[False]["dW"].abs().sum(1).max()      # noise of a cancelling sum - measured against the terms it adds up
+        err = float((a - b).abs().max() / ref)
+        assert err < 2e-5, (key, err)
