@@ -47,7 +47,7 @@ int svnet_slices_sum_f64(double* buf, int64_t L, void* stream);
  * changes its required length (200: sliced accumulators, SVNET_SLICED_LEN; 400: this header; 401: the totals of a sliced accumulator are
  * written by its consumer, svnet_slices_sum_*; 402: GX of svnet_v2s_bwd_*, gw of svnet_xyzblock_bwd_f32 and col_sum of svnet_gemm_f32 are sliced accumulators; 403: svnet_binweight_grad_f32 takes sliced inputs).  svnet_version() returns the value the
  * library was BUILT with: a caller compiled against another header must refuse to run (svnet_amd/_lib.py does).                   */
-#define SVNET_ABI_VERSION 405
+#define SVNET_ABI_VERSION 407
 int svnet_version(void);
 const char* svnet_last_error(void);
 
@@ -58,6 +58,8 @@ const char* svnet_last_error(void);
 typedef struct svnet_gate_fwd_job {
     const float* gin; const double* gin_f64; float* gin_out; float in_scale; const float* W0; const float* W2;
     int64_t B, Cin, H, Ov; float* h; float* gate;
+    const float* rows; int64_t R;   /* optional third source of the MLP's input (gin and gin_f64 NULL): gin_out[b,:] = mean over the R
+                                       rows of cloud b of rows [B*R, Cin] (sv_layers.py:179: s.mean over the points), kept for the backward */
 } svnet_gate_fwd_job;
 typedef struct svnet_gate_bwd_job {
     const float* dgate; const float* gate; const float* h; const float* gin; float in_scale; const float* W0; const float* W2;
@@ -488,7 +490,8 @@ int svnet_act_bwd_f32(const float* g, const float* y, int64_t n, int kind, float
  * fp32 into gin_out [B,Cin] first (kept by the caller for the backward).
  * Backward: dgin = out_scale * dL/d(in_scale*gin) (may be NULL), dW0 / dW2 ACCUMULATE (float atomics).       */
 int svnet_gate_mlp_fwd_f32(const float* gin, const double* gin_f64, float* gin_out, float in_scale, const float* W0,
-                           const float* W2, int64_t B, int64_t Cin, int64_t H, int64_t Ov, float* h, float* gate, void* stream);
+                           const float* W2, int64_t B, int64_t Cin, int64_t H, int64_t Ov, float* h, float* gate,
+                           const float* rows /* may be NULL */, int64_t R /* see svnet_gate_fwd_job */, void* stream);
 int svnet_gate_mlp_bwd_f32(const float* dgate, const float* gate, const float* h, const float* gin, float in_scale,
                            const float* W0, const float* W2, int64_t B, int64_t Cin, int64_t H, int64_t Ov, float out_scale,
                            float* dgin, float* dW0, float* dW2, void* stream);
@@ -561,6 +564,11 @@ int svnet_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n,
                         float weight_decay, int64_t step, void* stream);
 int svnet_sgd_step_f32(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float weight_decay,
                        int first_step, void* stream);
+/* The same steps with their step-dependent scalars read from DEVICE memory (a launch that can be part of a captured graph; the host
+ * refreshes `hyper` before every replay): adam hyper = [lr, beta1, beta2, eps, weight_decay, 1 - beta1^t, 1 / sqrt(1 - beta2^t)],
+ * sgd hyper = [lr, momentum, weight_decay, first_step (0 / 1)].                                                                    */
+int svnet_adam_step_dev_f32(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, void* stream);
+int svnet_sgd_step_dev_f32(float* p, const float* g, float* buf, int64_t n, const float* hyper, void* stream);
 
 /* ------------------------------------------------------------------ diagnostics (no reference counterpart)
  * One thread writes the constant-rate device clock (s_memrealtime: 100 MHz ticks) to *slot when the stream reaches it: the start

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVNET_DIAG_LIB") or os.path.join(_HERE, "libsvnet_hip.so")    # (SVNET_DIAG_LIB: an ablation build, tools/ only)
 _lib = None
-ABI_VERSION = 405       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
+ABI_VERSION = 407       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
 
 c_p = ctypes.c_void_p
 c_i64 = ctypes.c_int64
@@ -45,7 +45,7 @@ class GemmDesc(ctypes.Structure):
 class GateFwdJob(ctypes.Structure):
     """struct svnet_gate_fwd_job (include/svnet_hip.h): a gate MLP run beside a coefficient launch."""
     _fields_ = [("gin", c_p), ("gin_f64", c_p), ("gin_out", c_p), ("in_scale", c_f), ("W0", c_p), ("W2", c_p),
-                ("B", c_i64), ("Cin", c_i64), ("H", c_i64), ("Ov", c_i64), ("h", c_p), ("gate", c_p)]
+                ("B", c_i64), ("Cin", c_i64), ("H", c_i64), ("Ov", c_i64), ("h", c_p), ("gate", c_p), ("rows", c_p), ("R", c_i64)]
 
 
 class GateBwdJob(ctypes.Structure):
@@ -199,10 +199,12 @@ SIGNATURES = {
     "svnet_act_fwd_f32": (c_int, [c_p, c_i64, c_int, c_p, c_p]),
     "svnet_act_bwd_f32": (c_int, [c_p, c_p, c_i64, c_int, c_p, c_p]),
     "svnet_vlinear_stats_f32": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_p, c_p]),
-    "svnet_gate_mlp_fwd_f32": (c_int, [c_p, c_p, c_p, c_f, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
+    "svnet_gate_mlp_fwd_f32": (c_int, [c_p, c_p, c_p, c_f, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_i64, c_p]),
     "svnet_gate_mlp_bwd_f32": (c_int, [c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p, c_p]),
     "svnet_adam_step_f32": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_p]),
     "svnet_sgd_step_f32": (c_int, [c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_int, c_p]),
+    "svnet_adam_step_dev_f32": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
+    "svnet_sgd_step_dev_f32": (c_int, [c_p, c_p, c_p, c_i64, c_p, c_p]),
     "svnet_smooth_ce_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_f, c_p, c_p, c_p, c_i64, c_p]),
     "svnet_binhead_pack_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "svnet_binhead_fwd_f32": (c_int, [ctypes.POINTER(BinHeadDesc), c_p]),

@@ -348,6 +348,27 @@ class _PlaneCache:
             self.sig[key] = self._signature(ps)
         self.dirty = False
 
+    def rebuild_all(self, run=None):
+        """Every live entry re-packed now, whatever its state (run(rebuild) issues one; default: on the current stream) - what a
+        captured optimizer step records behind its update kernel (svnet_amd.train).  Returns the entries' keys."""
+        keys = []
+        for key in list(self.entries):
+            refs, _, rebuild = self.entries[key]
+            if any(r() is None for r in refs):
+                continue
+            (run or (lambda f: f()))(rebuild)
+            keys.append(key)
+        return keys
+
+    def mark_fresh(self, keys):
+        """The given entries have just been re-packed from the parameters' current values by someone else (a replayed graph)."""
+        for key in keys:
+            e = self.entries.get(key)
+            if e is not None:
+                ps = [r() for r in e[0]]
+                if all(p is not None for p in ps):
+                    self.sig[key] = self._signature(ps)
+
     def _join(self):
         if self.waited is not None:
             st = torch.cuda.current_stream()
@@ -1199,7 +1220,7 @@ class GateMLP(torch.autograd.Function):
         H, Ov = W0c.shape[0], W2c.shape[0]
         h = torch.empty((B, H), device=pooled.device, dtype=torch.float32)
         gate = torch.empty((B, Ov), device=pooled.device, dtype=torch.float32)
-        call("svnet_gate_mlp_fwd_f32", _p(pooled), None, None, 1.0, _p(W0c), _p(W2c), B, Cin, H, Ov, _p(h), _p(gate), _stream())
+        call("svnet_gate_mlp_fwd_f32", _p(pooled), None, None, 1.0, _p(W0c), _p(W2c), B, Cin, H, Ov, _p(h), _p(gate), None, 0, _stream())
         _tap_act(W0, 2, h)
         ctx.save_for_backward(pooled, W0c, W2c, h, gate)
         return gate
@@ -1216,6 +1237,44 @@ class GateMLP(torch.autograd.Function):
         call("svnet_gate_mlp_bwd_f32", _p(dgate), _p(gate), _p(h), _p(pooled), 1.0, _p(W0), _p(W2), B, Cin, H, Ov, 1.0,
              _p(dpooled) if dpooled is not None else None, _p(dW0), _p(dW2), _stream())
         return dpooled, dW0, dW2
+
+
+class GateMLPRows(torch.autograd.Function):
+    """gate = sigmoid(W2 . relu(W0 . mean_n s[b,n,:])) of an SVBlock on rows (sv_layers.py:179-183) with the mean over the cloud's rows
+    formed INSIDE the MLP's launch (Cin <= 256): the pooling pass in front of it was two launches (split, finish), its backward a
+    third - here the gradient of s is handed to autograd as the broadcast view it is."""
+
+    @staticmethod
+    def supported(s):
+        return s.is_cuda and s.dim() == 3 and s.shape[-1] <= 256 and s.shape[1] * s.shape[2] <= (1 << 18) and s.shape[1] > 0
+
+    @staticmethod
+    def forward(ctx, s, W0, W2):
+        s, W0c, W2c = _f32c(s), _f32c(W0), _f32c(W2)
+        B, Rr, Cin = s.shape
+        H, Ov = W0c.shape[0], W2c.shape[0]
+        pooled = torch.empty((B, Cin), device=s.device, dtype=torch.float32)
+        h = torch.empty((B, H), device=s.device, dtype=torch.float32)
+        gate = torch.empty((B, Ov), device=s.device, dtype=torch.float32)
+        call("svnet_gate_mlp_fwd_f32", None, None, _p(pooled), 1.0, _p(W0c), _p(W2c), B, Cin, H, Ov, _p(h), _p(gate), _p(s), Rr, _stream())
+        _tap_act(W0, 2, h)
+        ctx.save_for_backward(pooled, W0c, W2c, h, gate)
+        ctx.rows = Rr
+        return gate
+
+    @staticmethod
+    def backward(ctx, dgate):
+        pooled, W0, W2, h, gate = ctx.saved_tensors
+        dgate = _f32c(dgate)
+        B, Cin = pooled.shape
+        H, Ov = W0.shape[0], W2.shape[0]
+        zb = _zeros((H * Cin + Ov * H,), torch.float32, pooled.device)
+        dW0, dW2 = zb[:H * Cin].view(H, Cin), zb[H * Cin:].view(Ov, H)
+        dpooled = torch.empty_like(pooled) if ctx.needs_input_grad[0] else None
+        call("svnet_gate_mlp_bwd_f32", _p(dgate), _p(gate), _p(h), _p(pooled), 1.0, _p(W0), _p(W2), B, Cin, H, Ov, 1.0 / float(ctx.rows),
+             _p(dpooled) if dpooled is not None else None, _p(dW0), _p(dW2), _stream())
+        ds = None if dpooled is None else dpooled.unsqueeze(1).expand(B, ctx.rows, Cin)     # d mean / d s = 1 / R on every row
+        return ds, dW0, dW2
 
 
 class SmoothCE(torch.autograd.Function):

@@ -59,3 +59,7 @@ SIDE_PRIORITY = 0
 # (two alternating runs: one 8-wave workgroup per CU holding 100 KB of LDS shares the CUs worse with the scalar path beside it than the
 # three lighter kernels did), and nothing on sv_pointnet_cls (5.61 against 5.62): off.
 FUSE_VBN_STATS = False
+
+# SVBlock on rows, narrow s (the PointNet callers): the per-cloud mean of s the gate MLP starts from is formed inside the MLP's launch
+# (_ops.GateMLPRows) instead of by a pooling pass of two launches in front of it
+GATE_MEAN_INSIDE = True

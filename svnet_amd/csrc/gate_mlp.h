@@ -14,6 +14,35 @@ __device__ __forceinline__ void svnet_gate_fwd_block(const svnet_gate_fwd_job& j
         for (int c = tid; c < Cin; c += blockDim.x) j.gin_out[(size_t)b * Cin + c] = (float)j.gin_f64[(size_t)b * Cin + c];
         __syncthreads();
         gin = j.gin_out;
+    } else if (j.rows) {
+        // the mean over the cloud's R rows, formed here (a pooling pass of its own was two launches - split and finish - in front of
+        // this one): CW = the power of two >= Cin lanes walk a row, 256 / CW rows at a time, eight loads in flight; fixed order
+        __shared__ float part[256];
+        int cw = 1;
+        while (cw < Cin) cw <<= 1;                                      // (host: Cin <= 256)
+        const int RL = 256 / cw, c = tid & (cw - 1), rl = tid / cw;
+        const float* base = j.rows + (size_t)b * j.R * Cin;
+        float acc = 0.f;
+        if (c < Cin) {
+            int64_t r = rl;
+            for (; r + 7 * RL < j.R; r += 8 * RL) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = base[(r + u * RL) * Cin + c];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+            for (; r < j.R; r += RL) acc += base[r * Cin + c];
+        }
+        part[tid] = acc;
+        __syncthreads();
+        if (rl == 0 && c < Cin) {
+            float s = 0.f;
+            for (int q = 0; q < RL; ++q) s += part[q * cw + c];
+            j.gin_out[(size_t)b * Cin + c] = s / (float)j.R;
+        }
+        __syncthreads();
+        gin = j.gin_out;
     }
     const float* g = gin + (size_t)b * Cin;
     for (int r = tid; r < H; r += blockDim.x) {
@@ -75,7 +104,7 @@ static inline int svnet_gate_bwd_chunks(int64_t Cin, int64_t H, int64_t Ov) {
     return (int)chunks;
 }
 static inline bool svnet_gate_fwd_job_ok(const svnet_gate_fwd_job* j) {
-    return j && (j->gin || (j->gin_f64 && j->gin_out)) && j->W0 && j->W2 && j->h && j->gate && j->B >= 0 && j->Cin > 0 && j->H > 0 && j->Ov > 0 && j->H <= 256 && j->Ov <= 256;
+    return j && (j->gin || (j->gin_f64 && j->gin_out) || (j->rows && j->gin_out && j->R > 0 && j->Cin <= 256)) && j->W0 && j->W2 && j->h && j->gate && j->B >= 0 && j->Cin > 0 && j->H > 0 && j->Ov > 0 && j->H <= 256 && j->Ov <= 256;
 }
 static inline bool svnet_gate_bwd_job_ok(const svnet_gate_bwd_job* j) {
     return j && j->dgate && j->gate && j->h && j->gin && j->W0 && j->W2 && j->dW0 && j->dW2 && j->B >= 0 && j->Cin > 0 && j->H > 0 && j->Ov > 0 && j->H <= 256 && j->Ov <= 256;

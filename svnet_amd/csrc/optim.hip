@@ -38,7 +38,58 @@ __global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, co
     }
 }
 
+// The same steps with their step-dependent scalars read from DEVICE memory, so that the launch can be part of a captured graph (the
+// host refreshes `hyper` with one small asynchronous copy before every replay): adam [lr, beta1, beta2, eps, weight_decay, bc1,
+// 1/sqrt(bc2)], sgd [lr, momentum, weight_decay, first (0 / 1)].
+__global__ __launch_bounds__(256) void adam_step_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                            float* __restrict__ v, int64_t n, const float* __restrict__ hyper) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], rsqrt_bc2 = hyper[6];
+    const float step = lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        const float pi = p[i];
+        if (wd != 0.f) gi = fmaf(wd, pi, gi);
+        const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+        const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = pi - step * (mi / (sqrtf(vi) * rsqrt_bc2 + eps));
+    }
+}
+__global__ __launch_bounds__(256) void sgd_step_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                           int64_t n, const float* __restrict__ hyper) {
+    const float lr = hyper[0], momentum = hyper[1], wd = hyper[2];
+    const bool first = hyper[3] != 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        const float pi = p[i];
+        if (wd != 0.f) gi = fmaf(wd, pi, gi);
+        float bi = gi;
+        if (momentum != 0.f) {
+            bi = first ? gi : fmaf(momentum, buf[i], gi);
+            buf[i] = bi;
+        }
+        p[i] = pi - lr * bi;
+    }
+}
+
 }  // namespace
+
+extern "C" int svnet_adam_step_dev_f32(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, void* stream) {
+    SVNET_REQUIRE(p && g && m && v && hyper && n >= 0, SVNET_E_ARG, "svnet_adam_step_dev_f32: bad arguments");
+    if (n == 0) return SVNET_OK;
+    hipLaunchKernelGGL(adam_step_dev_kernel, dim3(svnet_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, hyper);
+    SVNET_CHECK_LAUNCH("adam_step_dev_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_sgd_step_dev_f32(float* p, const float* g, float* buf, int64_t n, const float* hyper, void* stream) {
+    SVNET_REQUIRE(p && g && buf && hyper && n >= 0, SVNET_E_ARG, "svnet_sgd_step_dev_f32: bad arguments");
+    if (n == 0) return SVNET_OK;
+    hipLaunchKernelGGL(sgd_step_dev_kernel, dim3(svnet_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, buf, n, hyper);
+    SVNET_CHECK_LAUNCH("sgd_step_dev_kernel");
+    return SVNET_OK;
+}
 
 extern "C" int svnet_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                                    float eps, float weight_decay, int64_t step, void* stream) {

@@ -666,12 +666,12 @@ __global__ __launch_bounds__(256) void gate_mlp_bwd_kernel(svnet_gate_bwd_job j)
 
 extern "C" int svnet_gate_mlp_fwd_f32(const float* gin, const double* gin_f64, float* gin_out, float in_scale, const float* W0,
                                       const float* W2, int64_t B, int64_t Cin, int64_t H, int64_t Ov, float* h, float* gate,
-                                      void* stream) {
-    SVNET_REQUIRE((gin || (gin_f64 && gin_out)) && W0 && W2 && h && gate && B >= 0 && Cin > 0 && H > 0 && Ov > 0, SVNET_E_ARG,
+                                      const float* rows, int64_t R, void* stream) {
+    SVNET_REQUIRE((gin || (gin_f64 && gin_out) || (rows && gin_out && R > 0 && Cin <= 256)) && W0 && W2 && h && gate && B >= 0 && Cin > 0 && H > 0 && Ov > 0, SVNET_E_ARG,
                   "svnet_gate_mlp_fwd_f32: bad arguments");
     SVNET_REQUIRE(H <= 256 && Ov <= 256, SVNET_E_UNSUPPORTED, "svnet_gate_mlp_fwd_f32: H, Ov must be <= 256");
     if (B == 0) return SVNET_OK;
-    const svnet_gate_fwd_job j = {gin, gin_f64, gin_out, in_scale, W0, W2, B, Cin, H, Ov, h, gate};
+    const svnet_gate_fwd_job j = {gin, gin_f64, gin_out, in_scale, W0, W2, B, Cin, H, Ov, h, gate, rows, R};
     hipLaunchKernelGGL(gate_mlp_fwd_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, j);
     SVNET_CHECK_LAUNCH("gate_mlp_fwd_kernel");
     return SVNET_OK;

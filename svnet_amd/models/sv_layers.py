@@ -281,8 +281,12 @@ class SVBlock(nn.Module):
         self.bn2 = VectorBN(out_dims[1])
 
     def _gate(self, s):
-        pooled = _ops.Pool.apply(s.reshape(s.shape[0], -1, s.shape[-1]), 1, 1)          # mean over all rows of a cloud
-        if self.gate[0].out_features <= 256 and self.gate[2].out_features <= 256:
+        small = self.gate[0].out_features <= 256 and self.gate[2].out_features <= 256
+        s3 = s.reshape(s.shape[0], -1, s.shape[-1])
+        if small and config.GATE_MEAN_INSIDE and _ops.GateMLPRows.supported(s3):
+            return _ops.GateMLPRows.apply(s3, self.gate[0].weight, self.gate[2].weight)   # (the mean over the rows inside the MLP's launch)
+        pooled = _ops.Pool.apply(s3, 1, 1)                                               # mean over all rows of a cloud
+        if small:
             return _ops.GateMLP.apply(pooled, self.gate[0].weight, self.gate[2].weight)  # -> [B, Cv_out]
         h = _ops.Act.apply(_ops.FpLinear.apply(pooled, self.gate[0].weight, None), 1)   # ReLU
         _ops._tap_act(self.gate[0].weight, 2, h)

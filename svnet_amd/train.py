@@ -240,6 +240,72 @@ class _FlatOptimizer:
                     dst.zero_()
 
 
+    # ---- the step as a captured graph.  An eager step is the update kernel plus, before the next forward, ~25 small launches that re-pack
+    # the binarized weights it changed (_ops.PLANES.refresh): 0.18 ms per step of latency-bound launches behind a 4.4 ms replay.  capture()
+    # records [update kernel -> every re-pack, spread over four streams] once; step() then costs one 32-byte copy of the step's scalars
+    # (learning rate, bias corrections) and one graph launch.  The update kernel reads those scalars from device memory.
+    def _hyper_values(self):
+        raise NotImplementedError
+
+    def _launch_dev(self):
+        raise NotImplementedError
+
+    def capture(self):
+        """Call after the model has run at least once (the packed forms exist) and the parameters live in their flat buffer."""
+        dev = self.p.device
+        self._hyper = torch.zeros(8, dtype=torch.float32, device=dev)
+        # (a ring of pinned staging slots: the host runs ahead of the device, so a slot is rewritten only after the copy that read it last)
+        self._hyper_ring = [(torch.zeros(8, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(16)]
+        self._hyper_slot = 0
+        self._helpers = [torch.cuda.Stream(device=dev) for _ in range(4)]
+        stream = torch.cuda.Stream(device=dev)
+        stream.wait_stream(torch.cuda.current_stream(dev))
+
+        def record():
+            self._launch_dev()
+            main = torch.cuda.current_stream(dev)
+            issued = [0]
+
+            def run(rebuild):
+                h = self._helpers[issued[0] % len(self._helpers)]
+                if issued[0] < len(self._helpers):
+                    h.wait_stream(main)                       # fork: behind the update kernel
+                issued[0] += 1
+                with torch.cuda.stream(h):
+                    rebuild()
+            keys = _ops.PLANES.rebuild_all(run)
+            for h in self._helpers[:issued[0]]:
+                main.wait_stream(h)                           # join
+            return keys
+        # (nothing is stepped here: the warm-up and the capture run with a zero learning rate and neutral bias corrections)
+        with torch.cuda.stream(stream):
+            self._put_hyper(self._neutral_hyper())
+            record()
+        torch.cuda.current_stream(dev).wait_stream(stream)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            self._keys = record()
+        self._graph = graph
+        return self
+
+    def _put_hyper(self, vals):
+        host, ev = self._hyper_ring[self._hyper_slot]
+        self._hyper_slot = (self._hyper_slot + 1) % len(self._hyper_ring)
+        ev.synchronize()                                      # (returns at once unless the device is 16 steps behind)
+        host[:len(vals)] = torch.tensor(vals, dtype=torch.float32)
+        self._hyper.copy_(host, non_blocking=True)
+        ev.record()
+
+    def _step_captured(self):
+        self._put_hyper(self._hyper_values())
+        self._graph.replay()
+        if set(_ops.PLANES.entries) <= set(self._keys):
+            _ops.PLANES.mark_fresh(self._keys)                # everything that exists was re-packed inside the graph
+        else:
+            _ops.PLANES.invalidate()                          # a packed form created after capture(): the eager refresh takes over
+
+
 class FlatAdam(_FlatOptimizer):
     """torch.optim.Adam(lr, betas=(0.9, 0.999), eps=1e-8, weight_decay) — L2 weight decay added to the gradient, bias-corrected
     moments, denominator sqrt(v_hat) + eps (main_cls_dgcnn.py:132-133, the optimizer of the binary models)."""
@@ -275,8 +341,22 @@ class FlatAdam(_FlatOptimizer):
         self._gather(state, "exp_avg", self.m)
         self._gather(state, "exp_avg_sq", self.v)
 
+    def _neutral_hyper(self):
+        return [0.0, 1.0, 1.0, self.eps, 0.0, 1.0, 1.0]      # lr 0, betas 1: parameters and both moments keep their values
+
+    def _hyper_values(self):
+        bc1 = 1.0 - self.b1 ** self.steps
+        bc2 = 1.0 - self.b2 ** self.steps
+        return [self.lr, self.b1, self.b2, self.eps, self.wd, bc1, 1.0 / math.sqrt(bc2)]
+
+    def _launch_dev(self):
+        _ops.call("svnet_adam_step_dev_f32", _ops._p(self.p), _ops._p(self.g), _ops._p(self.m), _ops._p(self.v), self.p.numel(),
+                  _ops._p(self._hyper), _ops._stream())
+
     def step(self):
         self.steps += 1
+        if getattr(self, "_graph", None) is not None:
+            return self._step_captured()
         _ops.PLANES.invalidate()                              # (the kernel writes the flat buffer behind autograd's version counters)
         _ops.call("svnet_adam_step_f32", _ops._p(self.p), _ops._p(self.g), _ops._p(self.m), _ops._p(self.v), self.p.numel(),
                   self.lr, self.b1, self.b2, self.eps, self.wd, self.steps, _ops._stream())
@@ -311,8 +391,20 @@ class FlatSGD(_FlatOptimizer):
         self._gather(state, "momentum_buffer", self.buf)
         self.steps = 1 if has else 0          # (torch.optim.SGD keeps no step count: a present buffer means "not the first step")
 
+    def _neutral_hyper(self):
+        return [0.0, 0.0, 0.0, 1.0]
+
+    def _hyper_values(self):
+        return [self.lr, self.momentum, self.wd, 1.0 if self.steps == 1 else 0.0]
+
+    def _launch_dev(self):
+        _ops.call("svnet_sgd_step_dev_f32", _ops._p(self.p), _ops._p(self.g), _ops._p(self.buf), self.p.numel(), _ops._p(self._hyper),
+                  _ops._stream())
+
     def step(self):
         self.steps += 1
+        if getattr(self, "_graph", None) is not None:
+            return self._step_captured()
         _ops.PLANES.invalidate()
         _ops.call("svnet_sgd_step_f32", _ops._p(self.p), _ops._p(self.g), _ops._p(self.buf), self.p.numel(), self.lr, self.momentum,
                   self.wd, int(self.steps == 1), _ops._stream())

@@ -344,3 +344,49 @@ def test_five_optimizer_steps_track_the_oracle(binary, hip_device, one_cpu_threa
                 Pg[name].copy_(val.float().double())
                 bufs[name].copy_(val.float().to(hip_device))
     assert opt.steps == 5 and abs(opt.lr) < 1e-12                               # cosine schedule reached eta_min
+
+
+@pytest.mark.parametrize("kind", ["adam", "sgd"])
+def test_captured_optimizer_step_equals_the_eager_one(kind, hip_device):
+    """FlatAdam / FlatSGD.capture(): [update kernel with its step scalars read from device memory -> every re-pack of the binarized
+    weights] as one graph.  Four steps from the SAME parameters and gradients, once with an eager optimizer and once with a captured
+    one (changing learning rate, step count 1 .. 4): parameters and optimizer state must agree to rounding, the loss of the next replay
+    must be the one a forced re-pack of every weight form gives (a stale form would change it), and capture() itself must move nothing.
+    (Step by step from a common state, not two free-running trajectories: a binarized net under Adam is chaotic - a gradient that is
+    pure rounding noise moves its parameter by +-lr - so two runs of the SAME code part ways after one step.)"""
+    from svnet_amd import _ops
+    from svnet_amd.train import FlatAdam, FlatParams, FlatSGD, TrainStep
+    model, x, y = _bench_model(hip_device, 2, N=256, k=8)
+    fp = FlatParams(model)
+    step = TrainStep(model, (x,), y)
+    step.capture()
+    step.run(all_reduce=False)
+    make = ((lambda: FlatAdam(fp, step.bucket, lr=2e-3, weight_decay=1e-4)) if kind == "adam"
+            else (lambda: FlatSGD(fp, step.bucket, lr=0.05, momentum=0.9, weight_decay=1e-4)))
+    eager, captured = make(), make()
+    before = fp.flat.clone()
+    captured.capture()
+    torch.cuda.synchronize()
+    assert torch.equal(before, fp.flat), "capture() moved the parameters"
+    assert float((captured.m if kind == "adam" else captured.buf).abs().max()) == 0.0, "capture() touched the optimizer state"
+    state_of = (lambda o: (o.m, o.v)) if kind == "adam" else (lambda o: (o.buf,))
+    losses = []
+    for it in range(4):
+        p_start, g = fp.flat.clone(), step.bucket.flat.clone()
+        eager.lr = captured.lr = eager.base_lr * (1.0 - 0.2 * it)
+        eager.step()
+        p_eager = fp.flat.clone()
+        fp.flat.copy_(p_start)
+        step.bucket.flat.copy_(g)
+        captured.step()
+        torch.cuda.synchronize()
+        assert float((fp.flat - p_eager).abs().max()) <= 1e-6, (it, float((fp.flat - p_eager).abs().max()))
+        for a_, b_ in zip(state_of(eager), state_of(captured)):
+            assert float((a_ - b_).abs().max()) <= 1e-6 * float(a_.abs().max()) + 1e-20, it
+        loss = float(step.run(all_reduce=False))                          # reads the forms the captured step re-packed
+        g_next = step.bucket.flat.clone()
+        _ops.PLANES.invalidate()
+        assert float(step.run(all_reduce=False)) == loss, "a packed weight form was stale after the captured step"
+        step.bucket.flat.copy_(g_next)
+        losses.append(loss)
+    assert len(set(losses)) == 4, "the steps did not change the loss"

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.svnet_version() == _lib.ABI_VERSION == 405
+    assert L.svnet_version() == _lib.ABI_VERSION == 407
     assert L.svnet_knn_workspace_bytes(2, 8, 3) >= (2 * 8 * 3 + 2 * 8) * 4
 
 
