@@ -8,8 +8,9 @@
 // statistics pass over y (svnet_colstats_f64 kind 1: 67 MB read at conv5 of the classifier, 17 launches a step in the PointNet callers)
 // is gone.  K <= 96 (the whole reduction and the whole weight fit in LDS: no k pipeline - the layer is bound by its 3 P (K + O) floats of
 // traffic, the next tile's rows travel in registers under the products), O <= 256.
-// Arithmetic: the fp32 activations are split exactly into three bf16 pieces (gemm_mfma.hip), the +-1 / 0 weights are exact in bf16, fp32
-// accumulation - the rows kernels' recipe.
+// Arithmetic: the fp32 activations are split exactly into three bf16 pieces (x = h + m + l, as in gemm_mfma.hip), the +-1 / 0 weights are
+// exact in bf16, fp32 accumulation - the rows kernels' recipe.  Measured: faster alone, not in the step - the product
+// path uses it only with config.FUSE_VBN_STATS.
 #include "common.h"
 
 namespace {
@@ -18,24 +19,6 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 __device__ __forceinline__ __bf16 vl_bf16_from_bits(uint32_t b) { return __builtin_bit_cast(__bf16, (unsigned short)b); }
-
-struct VlSplit3 {
-    bf16x8 h, m, l;
-};
-__device__ __forceinline__ VlSplit3 vl_split_frag(const float (&x)[8]) {          // x = h + m + l exactly (three bf16 pieces)
-    VlSplit3 s;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const uint32_t hu = __float_as_uint(x[j]) & 0xFFFF0000u;
-        const float r1 = x[j] - __uint_as_float(hu);
-        const uint32_t mu = __float_as_uint(r1) & 0xFFFF0000u;
-        const float r2 = r1 - __uint_as_float(mu);
-        s.h[j] = vl_bf16_from_bits(hu >> 16);
-        s.m[j] = vl_bf16_from_bits(mu >> 16);
-        s.l[j] = vl_bf16_from_bits(__float_as_uint(r2) >> 16);
-    }
-    return s;
-}
 
 struct VlinArgs {
     const float* v; const float* wb; const float* cs; float* y; double* sums;
