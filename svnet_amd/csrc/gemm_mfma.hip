@@ -1585,7 +1585,10 @@ extern "C" int svnet_edgeblock_wgrad_f32(const int16_t* n16, const uint8_t* slot
     a.kk = (int)k; a.kmagic = (uint32_t)((65536 + k - 1) / k); a.npts = E / k;
     static const bool aff2_off = getenv("SVNET_AFF2_OFF") != nullptr;   // (diagnostic switch: the one-p-tile-per-wave kernel for every width)
     if (Os == 128 && (a.qmask & 0x3FFu) == 0x3FFu && (E & 31) == 0 && !aff2_off) {       // wide layer, all ten column tiles in use: one output tile per workgroup
-        int64_t target = 256;                                             // one 8-wave workgroup per CU (126 KB of LDS)
+        // (one 8-wave workgroup per CU: 126 KB of LDS.  256 workgroups - one round, every CU held for the whole launch - measured 4.356 /
+        //  4.370 / 4.366 ms per step against 4.339 / 4.338 / 4.349 with 384: the shorter workgroups hand their CUs back to the gather on the main
+        //  stream half-way; 320: 4.351, 448: 4.361, 512: 4.406, 128: 4.417; profiles/r04_ab_aff2_target.log)
+        int64_t target = 384;
         if (const char* e = getenv("SVNET_AFF2_TARGET")) target = atoi(e);
         int64_t rpb = svnet_cdiv(svnet_cdiv(E, target), 64) * 64;
         if (rpb < 256) rpb = 256;
