@@ -256,6 +256,15 @@ def dgcnn_cls_legs(args, model, x, train, work, torch, _lib):
                 "frac": round(KNN_GATHER_STAGE_BYTES / t_stage / 1e9 / HBM_PEAK_GBS, 4),
                 "what": "SURVEY §8(d) bytes of the 4 k-NN + gather stages / (svnet_knn_f32 + 3 x svnet_knn_sv_f32 + xyzblock_fwd + 3 x edgeblock_fwd); the fused "
                         "kernels also do the SVBlock and the pooling of each stage, so this UNDER-states the gather's own bandwidth"}
+            # the exact k-NN against the pipe it runs on since round 4: the fmaf chain of every (query, candidate, channel) on
+            # v_mfma_f32_16x16x4_f32 (csrc/knn.hip knn_mf8_kernel); the selection and the table preparation are in the time, not in the flops
+            knn_flops = 2.0 * B_PER_GPU * N_POINTS * N_POINTS * (3 + 62 + 62 + 127)
+            stages["knn_exact_f32_mfma"] = {
+                "bound": "mfma", "flops_f32": knn_flops, "time_ms": round(t_knn_only * 1e3, 4),
+                "achieved": round(knn_flops / t_knn_only / 1e12, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(knn_flops / t_knn_only / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                "what": "2 B N^2 sum(C) flops of the four graphs (C = 3, 62, 62, 127) / (4 k-NN calls: table preparation + distances + exact "
+                        "top-k selection); the f32 matrix pipe equals the f32 vector rate and does not overlap vector work (DESIGN.md 4.6)"}
         # (i') the same stage in its API-compatible, MATERIALISING form (what SURVEY §8(d)'s byte count describes): the k-NN calls as
         # measured above plus the tier-1 gather kernels (svnet_edge_xyz_f32 / svnet_edge_diffcat_fwd_f32) writing the fp32 edge
         # tensors of the four stages, on this model's own point tables and graphs.  The fused path never performs this traffic; the
