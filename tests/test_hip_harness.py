@@ -364,3 +364,31 @@ def test_linear2_with_vectorbn_sums_matches_the_two_pass_chain(P, K, O, gated, h
             ref = outs[False]["dW"].abs().sum(1).max()      # noise of a cancelling sum - measured against the terms it adds up
         err = float((a - b).abs().max() / ref)
         assert err < 2e-5, (key, err)
+
+
+# ----------------------------------------------------------------------------- gate MLP with the mean over the rows inside its launch
+
+@pytest.mark.parametrize("B,R,Cin,H,Ov", [(32, 1024, 32, 5, 10), (8, 1000, 64, 10, 21), (4, 256, 200, 85, 170), (3, 1, 96, 16, 32)])
+def test_gate_mlp_on_rows_matches_pooling_then_mlp(B, R, Cin, H, Ov, hip_device):
+    """sv_layers.py:179-183 on rows: gate = sigmoid(W2 relu(W0 mean_n s[b,n,:])).  _ops.GateMLPRows (the mean formed inside the MLP's launch,
+    its gradient handed back as a broadcast view) against the chain it replaces - _ops.Pool (mean) then _ops.GateMLP - forward and
+    backward, the gradient of s summed with that of a second consumer as autograd does in an SVBlock."""
+    from svnet_amd import _ops
+    torch.manual_seed(B * R + Cin)
+    s0 = torch.randn(B, R, Cin, device=hip_device)
+    W0 = (torch.randn(H, Cin, device=hip_device) * 0.3)
+    W2 = (torch.randn(Ov, H, device=hip_device) * 0.3)
+    g = torch.randn(B, Ov, device=hip_device)
+    w_other = torch.randn(B, R, Cin, device=hip_device)
+    res = []
+    for fused in (False, True):
+        s = s0.clone().requires_grad_(True)
+        a, b = W0.clone().requires_grad_(True), W2.clone().requires_grad_(True)
+        gate = _ops.GateMLPRows.apply(s, a, b) if fused else _ops.GateMLP.apply(_ops.Pool.apply(s, 1, 1), a, b)
+        ((gate * g).sum() + (s * w_other).sum()).backward()
+        torch.cuda.synchronize()
+        res.append((gate.detach().clone(), s.grad.clone(), a.grad.clone(), b.grad.clone()))
+    assert _ops.GateMLPRows.supported(s0)
+    for x_, y_, name in zip(res[1], res[0], ("gate", "ds", "dW0", "dW2")):
+        err = float((x_ - y_).abs().max() / y_.abs().max().clamp_min(1e-30))
+        assert err < 1e-5, (name, err)
