@@ -16,7 +16,11 @@ TWO_STREAM_MIN_ROWS = 4096
 
 # Backward of the fused edge layers: entries of a reverse neighbour list that one wave of the gather kernel sums; longer lists
 # (hub points of the feature-space graphs) are cut into chunks summed by other waves.  0 = one wave per whole list.
-GATHER_CHUNK = 32
+# Round 4, re-measured on the current kernels (two alternating runs each, profiles/r04_ab_gather_chunk.log): 32: 4.396 / 4.388 ms,
+# 24: 4.400 / 4.404, 48: 4.378 / 4.381, 64: 4.379 / 4.368, 128: 4.376 / 4.371, 0: 4.367 / 4.363.  The deepest graph of the bench has 44 %
+# of its edges in lists longer than 32 (max in-degree 206: tools/diag_indegree.py), so at 32 nearly half of conv4's messages went
+# through the second, atomic launch; 128 keeps a bound on what one wave may be handed (a pathological hub) at the price of 0.008 ms.
+GATHER_CHUNK = 128
 
 # Backward of a dense (sign-weight / binarized) layer with many rows: the weight-gradient product on a helper stream beside the
 # input-gradient product.

@@ -93,11 +93,27 @@ def test_fused_backward_matches_layerwise(shape, hip_device):
     compare_case(grads[True], grads[False], 1e-3, "fused vs layerwise backward")
 
 
-def test_fused_backward_with_hub_points(hip_device):
+@pytest.mark.parametrize("chunk", [32, None, 0], ids=["chunk32", "default_chunk", "whole_lists"])
+def test_fused_backward_with_hub_points(chunk, hip_device):
     """A graph with hubs: the first few points sit at the origin of feature space, the others far out, so every point's
     neighbours are (itself and) those few - reverse lists of ~N entries, summed in chunks by the gather kernel's second launch
-    (svnet_knn_reverse_i32's overflow items), against the layer-wise path on the same inputs."""
+    (svnet_knn_reverse_i32's overflow items), against the layer-wise path on the same inputs.  With config.GATHER_CHUNK = 32 (four
+    overflow chunks per hub), the default (one) and 0 (one wave walks the whole list, no second launch)."""
+    from svnet_amd import config
     shape = ((32, 10), (64, 21), 2, 150, 8)
+    grads, deg = {}, None
+    old_chunk = config.GATHER_CHUNK
+    if chunk is not None:
+        config.GATHER_CHUNK = chunk
+    try:
+        grads, deg = _hub_grads(shape, hip_device)
+    finally:
+        config.GATHER_CHUNK = old_chunk
+    assert int(deg.max()) > 100, "the construction should make hubs (max in-degree %d)" % int(deg.max())
+    compare_case(grads[True], grads[False], 1e-3, "fused vs layerwise backward, hub graph")
+
+
+def _hub_grads(shape, hip_device):
     grads, deg = {}, None
     for fuse in (True, False):
         blk, params, s, v, (in_dims, out_dims, B, N, k) = _make(shape, hip_device, True, "fused_hub")
@@ -118,8 +134,7 @@ def test_fused_backward_with_hub_points(hip_device):
         for n, p in blk.named_parameters():
             g["d:" + n] = p.grad.cpu().numpy()
         grads[fuse] = g
-    assert int(deg.max()) > 100, "the construction should make hubs (max in-degree %d)" % int(deg.max())
-    compare_case(grads[True], grads[False], 1e-3, "fused vs layerwise backward, hub graph")
+    return grads, deg
 
 
 # ----------------------------------------------------------------------------- fused FIRST layer (xyz -> init_scalar -> conv1 -> pool)
