@@ -64,6 +64,11 @@ def parse_args():
     ap.add_argument("--force-collective", action="store_true",
                     help="--gpus 1 only: run the RCCL all-reduce(avg) of the real gradient bucket inside the timed loop at world size 1 "
                          "(the collective's fixed cost on this box: collective_us)")
+    ap.add_argument("--selftest-cpu", action="store_true",
+                    help="NOT a benchmark: drive this file's rank plumbing (spawn, world-size check, process group, barrier, all_gather of the "
+                         "per-rank clocks, max over ranks, rank-0-only JSON line, collective_us) on gloo / CPU with a stand-in step - "
+                         "tests/test_host.py rehearses the N > 1 path with it where no GPU exists")
+    ap.add_argument("--selftest-fail-rank", type=int, default=-1, help="--selftest-cpu: this rank exits with code 7 before the timed region")
     return ap.parse_args()
 
 
@@ -81,11 +86,17 @@ def spawn_ranks(args):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     try:
-        for p in procs:
-            code = p.wait()
-            rc = rc or code
-            if code != 0:
-                break
+        # poll ALL children: a rank that dies while the others sit in a collective must take the job down at once (waiting for rank 0
+        # first would hang until the collective's timeout)
+        live = list(procs)
+        while live and rc == 0:
+            for p in list(live):
+                code = p.poll()
+                if code is not None:
+                    live.remove(p)
+                    rc = rc or code
+            if live and rc == 0:
+                time.sleep(0.05)
     finally:
         for p in procs:
             if p.poll() is None:
@@ -524,24 +535,58 @@ def train_loop_leg(model, inputs, y, loss_fn, torch, steps=20):
                     "replay_only = the first graph alone (nothing stale, nothing re-packed)" % steps}
 
 
-def main():
-    args = parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args))
+class _SelftestStep:
+    """Stand-in for svnet_amd.train.TrainStep in --selftest-cpu runs (same surface: capture / run / fwd_bwd / bucket / loss): a tiny
+    torch CPU model whose gradients live in the product's GradBucket and go through the product's all_reduce_mean() on gloo."""
+
+    def __init__(self, rank):
+        import torch
+        from svnet_amd.dist import GradBucket
+        torch.manual_seed(0)                                          # same weights on every rank
+        self.model = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.BatchNorm1d(32), torch.nn.ReLU(), torch.nn.Linear(32, 40))
+        gen = torch.Generator().manual_seed(100 + rank)               # rank-indexed inputs
+        self.x, self.y = torch.randn(32, 16, generator=gen), torch.randint(0, 40, (32,), generator=gen)
+        self.bucket = GradBucket(self.model.parameters())
+        self.graph, self.loss = None, None
+
+    def capture(self):
+        return self
+
+    def fwd_bwd(self, planes_external=False):
+        import torch
+        self.bucket.zero()
+        loss = torch.nn.functional.cross_entropy(self.model(self.x), self.y)
+        loss.backward()
+        self.loss = loss.detach()
+        return self.loss
+
+    def run(self, all_reduce=True):
+        loss = self.fwd_bwd()
+        if all_reduce:
+            self.bucket.all_reduce_mean()
+        return loss
+
+
+def rank_main(args):
+    """One rank of the job (the whole job at --gpus 1).  The product run talks RCCL ("nccl") from cuda:LOCAL_RANK; --selftest-cpu runs
+    the SAME control flow - process group, world-size check, barrier, per-rank clocks, max over ranks, rank-0-only line - on gloo / CPU
+    with a stand-in step, so that the N > 1 path has executed before the driver's 8-GPU node runs it (tests/test_host.py)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
-        sys.exit(2)
+        return 2
+    selftest = args.selftest_cpu
     wl = WORKLOADS[args.workload]
     B, N, k = wl["B"], wl["N"], wl["k"]
     if args.force_collective and world != 1:
         print("bench.py: --force-collective is the world-size-1 leg (the N > 1 runs always reduce)", file=sys.stderr)
-        sys.exit(2)
+        return 2
 
     import torch
     import torch.distributed as dist
+    backend = "gloo" if selftest else "nccl"
     collective = world > 1 or args.force_collective
     if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -550,27 +595,43 @@ def main():
                 sk.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if selftest:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
         if dist.get_world_size() != args.gpus:                          # the collective's own group, not the environment
-            print("bench.py: --gpus %d but the RCCL group has %d ranks" % (args.gpus, dist.get_world_size()), file=sys.stderr)
-            sys.exit(2)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+            print("bench.py: --gpus %d but the %s group has %d ranks" % (args.gpus, backend, dist.get_world_size()), file=sys.stderr)
+            return 2
+    if selftest:
+        dev = torch.device("cpu")
 
-    from svnet_amd import _lib, config
-    from svnet_amd.train import ForwardStep, TrainStep
-    _lib.lib()                                                        # fail loudly if the HIP library is missing
+        def device_sync():
+            pass
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        device_sync = torch.cuda.synchronize
 
-    wl, model, inputs, y, loss_fn = build_workload(args.workload, dev, rank)
-    x = inputs[0]
-
-    train = TrainStep(model.train(), inputs, y, loss_fn)
-    if args.mode == "train":
+    if selftest:
+        _lib = config = None
+        model = inputs = y = loss_fn = x = None
+        train = _SelftestStep(rank)
+        if rank == args.selftest_fail_rank:
+            print("bench.py: rank %d fails on request (--selftest-fail-rank)" % rank, file=sys.stderr)
+            return 7
+    else:
+        from svnet_amd import _lib, config
+        from svnet_amd.train import ForwardStep, TrainStep
+        _lib.lib()                                                        # fail loudly if the HIP library is missing
+        wl, model, inputs, y, loss_fn = build_workload(args.workload, dev, rank)
+        x = inputs[0]
+        train = TrainStep(model.train(), inputs, y, loss_fn)
+    if args.mode == "train" or selftest:
         work = train
     else:
         work = ForwardStep(model, inputs)
     graph_ok = False
-    if not args.no_graph:
+    if not args.no_graph and not selftest:
         try:
             work.capture()
             graph_ok = True
@@ -578,13 +639,13 @@ def main():
             if rank == 0:
                 print("graph capture failed, running eagerly: %r" % (e,), file=sys.stderr)
             work.graph = None
-            torch.cuda.synchronize()
+            device_sync()
 
     def barrier():
-        torch.cuda.synchronize()
+        device_sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
     def timed(step_fn, steps, warmup):
         for _ in range(warmup):
@@ -611,25 +672,31 @@ def main():
     elapsed, per_rank = timed(run_step, args.steps, args.warmup)
     collective_us = None
     if collective and args.mode == "train":
-        # the collective alone: HIP events around `steps` back-to-back all-reduces of the bucket, after the timed region
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # the collective alone: `steps` back-to-back all-reduces of the bucket after the timed region (HIP events on the device)
         for _ in range(3):
             train.bucket.all_reduce_mean(force=True)
         barrier()
-        e0.record()
-        for _ in range(args.steps):
-            train.bucket.all_reduce_mean(force=True)
-        e1.record()
-        torch.cuda.synchronize()
-        collective_us = round(e0.elapsed_time(e1) / args.steps * 1e3, 1)
+        if selftest:
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                train.bucket.all_reduce_mean(force=True)
+            collective_us = round((time.perf_counter() - t0) / args.steps * 1e6, 1)
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.steps):
+                train.bucket.all_reduce_mean(force=True)
+            e1.record()
+            torch.cuda.synchronize()
+            collective_us = round(e0.elapsed_time(e1) / args.steps * 1e3, 1)
     loss = float(train.loss) if (args.mode == "train" and train.loss is not None) else None
     if loss is not None and not (loss == loss and abs(loss) < 1e6):
         print("bench.py: non-finite loss %r in the timed region" % loss, file=sys.stderr)
-        sys.exit(3)
+        return 3
 
     # secondary number: forward-only eval throughput next to the headline one (rank-local graph, after the timed region)
     fwd_only = None
-    if args.mode == "train" and world == 1:
+    if args.mode == "train" and world == 1 and not selftest:
         fs = ForwardStep(model, inputs)
         try:
             if not args.no_graph:
@@ -642,10 +709,10 @@ def main():
                     "what": "forward only, eval(), no_grad, same model and batch"}
         model.train()
 
-    stages = per_launch = None
+    stages = per_launch = primary = None
     launches = None
     bucket_mb = train.bucket.flat.numel() * 4 / 1e6
-    if rank == 0:
+    if rank == 0 and not selftest:
         if args.workload == "dgcnn_cls":
             per_launch, stages = dgcnn_cls_legs(args, model, x, train, work, torch, _lib)
             primary = per_launch if args.mode == "train" else (stages or {}).get("knn_gather_forward")
@@ -654,7 +721,8 @@ def main():
         if graph_ok:
             launches = graph_kernel_nodes(work)
 
-    extras = args.workload == "dgcnn_cls" and args.mode == "train" and world == 1 and not args.no_extras and not args.no_graph
+    extras = (args.workload == "dgcnn_cls" and args.mode == "train" and world == 1 and not args.no_extras and not args.no_graph
+              and not selftest)
     others = loop_leg = None
     if rank == 0 and extras:
         try:
@@ -682,18 +750,25 @@ def main():
             "config": {"workload": "%s %s, B=%d per GPU, N=%d, k=%d"
                                    % (wl["name"], "fwd+loss+bwd" if args.mode == "train" else "forward only (eval)", B, N, k),
                        "global_batch": B * world, "parallelism": "dp%d" % world,
-                       "collective": ("RCCL all-reduce(avg) of one %.2f MB gradient bucket per step, world size %d"
-                                      % (bucket_mb, dist.get_world_size())) if collective else "none (1 rank)",
+                       "collective": ("%s all-reduce(avg) of one %.2f MB gradient bucket per step, world size %d"
+                                      % ("RCCL" if backend == "nccl" else backend, bucket_mb, dist.get_world_size())) if collective else "none (1 rank)",
                        "rccl_world": dist.get_world_size() if collective else 1,      # the collective group's own size (1 = no group)
                        "collective_us": collective_us,
                        "launch": "hipGraph replay" if graph_ok else "eager",
-                       "graph_nodes": launches,
-                       # which binarized-linear kernel serves the dense layers with >= 1024 rows (both give identical integer counts)
-                       "binlinear": ("i8_mfma (>= 1024 rows) + xnor (head)" if config.BINLINEAR_MFMA else "xnor") if wl["binary"] else "none (fp)"},
+                       "graph_nodes": launches},
             "per_rank_ms_per_step": [round(t / args.steps * 1e3, 3) for t in per_rank],
             "roofline": primary,
         }
-        if args.workload == "dgcnn_cls" and args.mode == "train":
+        if selftest:
+            # NOT a measurement of the product: the line only shows that the rank plumbing ran end to end
+            out.update({"metric": "SELFTEST (gloo/CPU stand-in step, not the product)", "data": "selftest", "dtype": "f32",
+                        "selftest": True})
+            out["config"]["workload"] = "rank-plumbing self-test: stand-in torch CPU step, B=%d per rank" % B
+        else:
+            # which binarized-linear kernel serves the dense layers with >= 1024 rows (both give identical integer counts)
+            out["config"]["binlinear"] = (("i8_mfma (>= 1024 rows) + xnor (head)" if config.BINLINEAR_MFMA else "xnor")
+                                          if wl["binary"] else "none (fp)")
+        if args.workload == "dgcnn_cls" and args.mode == "train" and not selftest:
             out["metric"] = "point-clouds/sec fwd+bwd, sv_dgcnn_cls B=32 N=1024 k=20"           # BASELINE.json's wording
         if loss is not None:
             out["loss"] = round(loss, 6)
@@ -707,13 +782,21 @@ def main():
                 out["train_loop_ms_per_step"] = loop_leg["train_loop_ms_per_step"]
         if others:
             out["other_workloads"] = others
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not selftest:
             out["cpu_baseline"] = cpu_baseline(wl, sample_b=4 if wl["model"] != "sv_dgcnn_pseg" else 2)
         print(json.dumps(out))
         sys.stdout.flush()
     if collective:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    sys.exit(rank_main(args))
 
 
 if __name__ == "__main__":

@@ -94,12 +94,17 @@ TRAIN_CASES = [c for c in C.MODEL_CASES if c[0].endswith("_small") and c[0] != "
     # knn_main<16,4,...>, the conv4 tile kernel <0,8,44>, mfma_tn_aff2, chunked reverse lists, sliced sums over thousands of workgroups -
     # chained against the oracle, where the other cases stop at N = 128 (sv_dgcnn_cls.py:46-82)
     ("dgcnn_bin_n1024", "sv_dgcnn_cls", True, 8, 1024, 20),
+    # BASELINE config 5's shape (N = 2048, k = 40; sv_dgcnn_partseg.py:80-128): the k = 40 backward instantiations -
+    # edgeblock_bwd_kernel<0,8,48> / <0,4,44> / <0,2,44>, the N = 2048 reverse lists, the vector-form k-NN with its merged selection,
+    # the rows head on 2144 columns - chained against the oracle in TRAIN mode (rounds 1-4 stopped at N = 128 there).  B = 4: the
+    # per-cloud blocks conv6 / conv7 normalise over B rows, so B = 2 would be the ill-conditioned pseg_fp_small again
+    ("pseg_bin_n2048", "sv_dgcnn_pseg", True, 4, 2048, 40),
 ]
 # cases held to the north-star tolerance itself (1e-3) on every tensor, whatever the yard-sticks say
 STRICT = ("dgcnn_bin_small", "dgcnn_fp_small", "pseg_bin_small", "dgcnn_bin_b16", "dgcnn_bin_b16b", "dgcnn_bin_b8", "dgcnn_fp_b16",
-          "pseg_bin_b32", "pseg_fp_b32", "dgcnn_bin_n1024")
+          "pseg_bin_b32", "pseg_fp_b32", "dgcnn_bin_n1024", "pseg_bin_n2048")
 WIDER_CERTIFICATE = ("ppseg_fp_b16",)          # the one case whose decision certificate allows 30 instead of 20 rms of fp32 noise (see below)
-NO_SENSITIVITY_LEG = ("dgcnn_bin_n1024",)      # STRICT cases never use the float64 sensitivity (a third oracle step: ~1 min at this size)
+NO_SENSITIVITY_LEG = ("dgcnn_bin_n1024", "pseg_bin_n2048")     # STRICT cases never use the float64 sensitivity (a third oracle step: ~1 min at this size)
 YARDSTICK = 3.0         # a tensor may be this many times further from the float64 truth than the fp32 oracle is ...
 SENSITIVITY = 10.0      # ... or this many times what the float64 truth itself moves when its input moves by one part in 1e7
 
@@ -222,16 +227,19 @@ def test_a_one_percent_gradient_error_is_caught(hip_device):
     assert [b[3] for b in bad] == picked, (bad, picked)
 
 
-@pytest.mark.parametrize("shape", [((64, 21), (128, 42), 2, 1024, 20), ((32, 10), (32, 10), 2, 1024, 20), ((32, 10), (64, 21), 1, 512, 20)],
-                         ids=["conv4", "conv2", "conv3"])
+@pytest.mark.parametrize("shape", [((64, 21), (128, 42), 2, 1024, 20), ((32, 10), (32, 10), 2, 1024, 20), ((32, 10), (64, 21), 1, 512, 20),
+                                   # sv_dgcnn_partseg's widths at ITS size (sv_dgcnn_partseg.py:52-58, N = 2048, k = 40)
+                                   ((32, 16), (32, 16), 2, 2048, 40), ((32, 16), (64, 24), 1, 2048, 40), ((64, 24), (128, 40), 2, 2048, 40)],
+                         ids=["conv4", "conv2", "conv3", "pseg_conv2", "pseg_conv3", "pseg_conv4"])
 def test_fused_edge_block_backward_matches_exact_oracle(shape, hip_device):
-    """get_graph_feature_sv -> SVBlock(binary) -> svpool at the headline widths and N=1024, k=20: outputs, input gradients and every
+    """get_graph_feature_sv -> SVBlock(binary) -> svpool at the headline widths and N=1024, k=20, and at config 5's widths with
+    N=2048, k=40: outputs, input gradients and every
     parameter gradient of the FUSED path (what bench.py runs) against the exact-STE oracle, element-wise."""
     from svnet_amd.models.sv_layers import SVBlock
     from svnet_amd.models.utils.sv_util import get_graph_feature_sv, svpool
     (Cs, Cv), (Os, Ov), B, N, k = shape
     in_dims, out_dims = (2 * Cs, 2 * Cv), (Os, Ov)
-    tag = "fused_full_%d" % Os
+    tag = "fused_full_%d" % Os if N <= 1024 else "fused_pseg_%d_n%d" % (Os, N)
     params = H.module_params("SVBlock", (in_dims, out_dims, True), tag)
     params["linear1.beta"][:, ::4] = 0.0
     with contextlib.redirect_stdout(io.StringIO()):

@@ -1,7 +1,9 @@
 """CPU tests of the host side: synthetic data, the C-ABI library surface, the no-fallback rule and the
 data-parallel gradient bucket (gloo, world size 2)."""
 import os
+import json
 import re
+import socket
 import subprocess
 import sys
 
@@ -167,3 +169,53 @@ def test_deferred_weight_gradients_only_when_autograd_merely_adopts_them():
         post = Two(False)
         post.b.weight.register_post_accumulate_grad_hook(lambda p: None)
         assert not TrainStep(post, (x,), y)._deferral_is_safe()
+
+
+def _run_bench(argv, env_extra=None, launcher=False, timeout=300):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    cmd = [sys.executable]
+    if launcher:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    p = subprocess.run(cmd + [os.path.join(ROOT, "bench.py")] + argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    return p.returncode, lines, p.stderr.decode()
+
+
+@pytest.mark.parametrize("launcher", [False, True], ids=["self_spawned", "torch_distributed_run"])
+def test_bench_rank_plumbing_runs_end_to_end_on_two_gloo_ranks(launcher):
+    """The N > 1 path of bench.py (the thing that replaces nn.DataParallel, main_cls_dgcnn.py:125,182-184) has never run on RCCL from this
+    container.  Its control flow is the same function for both backends (bench.rank_main): two ranks on gloo / CPU with a stand-in step
+    go through spawn (or the driver's `python -m torch.distributed.run` launch), the world-size check on the collective's own group, the
+    barrier-bracketed timed region, the all_gather of the per-rank clocks, the max over ranks, the product's GradBucket.all_reduce_mean()
+    and the rank-0-only JSON line with `rccl_world` and `collective_us`."""
+    rc, lines, err = _run_bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--selftest-cpu"], launcher=launcher)
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1, (lines, err[-2000:])                      # rank 0 only, ONE line
+    out = json.loads(lines[0])
+    assert out["selftest"] is True and out["data"] == "selftest"      # can never be mistaken for a measurement
+    assert out["n_gpus"] == 2 and out["config"]["rccl_world"] == 2 and out["config"]["parallelism"] == "dp2"
+    assert out["steps"] == 4 and out["warmup"] == 1 and out["scaling"] == "weak" and out["config"]["global_batch"] == 64
+    per_rank = out["per_rank_ms_per_step"]
+    assert len(per_rank) == 2 and abs(out["ms_per_step"] - max(per_rank)) < 1e-9     # the job's time is the slowest rank's
+    assert abs(out["value"] - 64 * 1e3 / out["ms_per_step"]) < 1e-2 * out["value"]   # whole-job throughput: all ranks' clouds / that time
+    assert out["config"]["collective_us"] is not None and out["config"]["collective_us"] > 0
+    assert "cpu_baseline" not in out and "other_workloads" not in out                # world-1-only legs stay out of the N > 1 line
+
+
+def test_bench_parent_fails_when_a_rank_fails_and_refuses_a_wrong_world_size():
+    """A rank that dies while the other sits in a collective must end the job with ITS exit code at once (the parent polls every child and
+    kills the rest - waiting for rank 0 first would hang until the collective's timeout); `--gpus N` with another WORLD_SIZE is refused."""
+    import time as _time
+    t0 = _time.time()
+    rc, lines, err = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--selftest-cpu", "--selftest-fail-rank", "1"])
+    assert rc == 7 and not lines, (rc, lines, err[-1000:])
+    assert _time.time() - t0 < 120
+    rc, lines, err = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--selftest-cpu"],
+                                env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc == 2 and not lines and "WORLD_SIZE" in err
