@@ -436,6 +436,7 @@ def end_step():
     PLANES.end()
     DEFERRED.active = False
     DEFERRED.keep.clear()
+    DEFERRED.seen.clear()
 
 
 class _Deferred:
@@ -450,11 +451,23 @@ class _Deferred:
     def __init__(self):
         self.active = False
         self.keep = []
+        self.seen = set()
+
+    def first_use(self, *params):
+        """True while none of `params` (a layer's weights) has been handed an unwritten gradient in this backward.  A module applied
+        twice in one forward - or one parameter read by two Functions - gets two gradients, which autograd ADDS on the main stream:
+        the second backward must therefore take the joined schedule (its final join also covers the first, deferred chain).  This is
+        the run-time half of TrainStep._deferral_is_safe(), which can only see parameters registered under two names."""
+        keys = [p.data_ptr() for p in params if p is not None]
+        dup = any(k in self.seen for k in keys)
+        self.seen.update(keys)
+        return not dup
 
     def join(self, dev):
         if self.keep:
             torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
             self.keep.clear()
+        self.seen.clear()
 
 
 DEFERRED = _Deferred()
@@ -762,11 +775,10 @@ class V2SCat(torch.autograd.Function):
     the gradient on as a view and reads the Vector2Scalar part where it lies (svnet_v2s_bwd_ld_f32)."""
 
     @staticmethod
-    def forward(ctx, s, v, W, scale, training=True, clouds=0, mean_on_side=False):
+    def forward(ctx, s, v, W, scale, training=True, clouds=0):
         """clouds > 0: also returns mean(s) over each cloud's rows [clouds, Cs] (the gate's input, sv_layers.py:179): s then has ONE
         consumer in the autograd graph, and the backward writes its gradient once - the cat gradient's s columns plus the mean's
-        broadcast - instead of a broadcast pass and a strided add of two gradients in front of the layer's backward.
-        mean_on_side: the mean is computed on the side stream (its consumer - the gate MLP, then VectorBN - lives there)."""
+        broadcast - instead of a broadcast pass and a strided add of two gradients in front of the layer's backward."""
         _hip(s, v, W, scale)
         ctx.training = bool(training)
         v3 = _f32c(v).reshape(-1, 3, v.shape[-1])
@@ -781,12 +793,6 @@ class V2SCat(torch.autograd.Function):
         else:
             sc, w_eff = None, W
         out = torch.empty((M, Cs + C * J), dtype=torch.float32, device=v.device)
-        s_mean = None
-        if clouds and mean_on_side:
-            main, side = torch.cuda.current_stream(v.device), _side_stream(v.device)
-            side.wait_stream(main)                       # (s2 may be a copy this stream has just made)
-            with torch.cuda.stream(side):
-                s_mean, _ = pool_raw(s2, clouds, M // clouds, Cs, 1)
         call("svnet_v2s_cat_fwd_f32", _p(v3), _p(w_eff), _p(s2), Cs, M, C, J, _p(out), Cs + C * J, _stream())
         ctx.save_for_backward(v3, W, w_eff, sc)
         ctx.meta = (M, C, J, Cs, s.shape, v.shape, None if scale is None else scale.shape)
@@ -794,8 +800,7 @@ class V2SCat(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         cat = out.view(s.shape[:-1] + (Cs + C * J,))
         if clouds:
-            if s_mean is None:
-                s_mean, _ = pool_raw(s2, clouds, M // clouds, Cs, 1)
+            s_mean, _ = pool_raw(s2, clouds, M // clouds, Cs, 1)
             return cat, s_mean
         return cat
 
@@ -824,7 +829,7 @@ class V2SCat(torch.autograd.Function):
         else:
             call("svnet_slices_sum_f32", _p(gxb), J * C, _stream())
             dW, dsc = gxb[:J * C].view(J, C), None
-        return ds, dv.view(vshape), dW, dsc, None, None, None
+        return ds, dv.view(vshape), dW, dsc, None, None
 
 
 class VProject(torch.autograd.Function):
@@ -1637,7 +1642,7 @@ class EdgeBlock(torch.autograd.Function):
             # alternating runs): the prelude and the vector path, which the critical path waits for, no longer share the CUs with them
             call("svnet_knn_reverse_i32", _p(idx), B, N, k, _p(rev_range), _p(rev_edge), _p(rev_src), GATHER_CHUNK, _p(ovf_items), _p(ovf_count),
                  _stream())
-            vec_done = side.record_event() if DEFERRED.active else None     # (also covers the reverse lists: same stream)
+            vec_done = side.record_event() if DEFERRED.active else None     # (also covers the reverse lists: same stream; unused on the joined schedule)
         d.parts = 2
         call("svnet_edgeblock_bwd_f32", ctypes.byref(d), _stream())
 
@@ -1663,7 +1668,7 @@ class EdgeBlock(torch.autograd.Function):
                 gemm(320, Os, E, a_planes=(x_sign, x_nz), B=dn_out, b_rs=Os, b_cs=1, C=GXp, ldc=1, c_cs=320, accumulate=True,
                      tern_tile_mask=used)
 
-        if DEFERRED.active:
+        if DEFERRED.active and DEFERRED.first_use(W1, W2, Wz, Wg0, Wg2, g1, g2):
             # the step gathers the parameter gradients once, after the whole backward: the weight-gradient chain stays on the side
             # stream, unjoined, and the main stream carries what the NEXT layer's backward waits for (message sums -> dv product)
             with torch.cuda.stream(side):

@@ -45,9 +45,8 @@ FUSE_HEAD = True
 # (svnet_amd._ops._Deferred); False = every backward joins before it returns
 DEFER_WGRAD = True
 VEC_EARLY = True
-# SVBlock on rows (two streams): the gate's chain - per-cloud mean of s, MLP - on the side stream behind linear2's product, beside linear1
-# on the main stream (its only consumer, VectorBN, lives on the side stream)
-GATE_ON_SIDE = False     # measured: 4.57 - 4.60 ms with the gate on the main stream, 4.62 on the side (the vector path is then the longer one)
+# (round 4 measured the gate's chain - per-cloud mean of s, MLP - of an SVBlock on rows on the side stream behind linear2's product:
+#  4.62 ms against 4.57 - 4.60 with the gate on the main stream; the switch and its code path are gone.)
 # sign-weight products with many rows and more than 128 columns go to the LDS-tiled rows kernel from this K on (it needs K >= 64)
 ROWS2_MIN_K = 64
 

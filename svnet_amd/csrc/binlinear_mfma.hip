@@ -251,13 +251,11 @@ extern "C" int svnet_binlinear_i8_fwd_f32(const float* x, int64_t ldx, const flo
     const int ntw = O <= 128 ? 1 : (O <= 256 ? 2 : 4);
     const dim3 grid((unsigned)svnet_cdiv(M, BM), (unsigned)svnet_cdiv(O, 128 * ntw));
     const size_t lds = (size_t)BM * LDA + (size_t)128 * ntw * LDA + 3 * BM * 2 * sizeof(uint64_t);
-    static bool attr_set = false;                       // more than 64 KiB of dynamic LDS needs an explicit opt-in (NTW = 4: 96 KiB)
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&binlinear_i8_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BM * LDA + 128 * LDA + 6144));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&binlinear_i8_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BM * LDA + 256 * LDA + 6144));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&binlinear_i8_fwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BM * LDA + 512 * LDA + 6144));
-        attr_set = true;
-    }
+    bool ok = true;                                      // more than 64 KiB of dynamic LDS needs an explicit opt-in (NTW = 4: 96 KiB), per device
+    if (ntw == 1) SVNET_LDS_OPTIN(ok, BM * LDA + 128 * LDA + 6144, "binlinear_i8_fwd_kernel<1>", reinterpret_cast<const void*>(&binlinear_i8_fwd_kernel<1>));
+    else if (ntw == 2) SVNET_LDS_OPTIN(ok, BM * LDA + 256 * LDA + 6144, "binlinear_i8_fwd_kernel<2>", reinterpret_cast<const void*>(&binlinear_i8_fwd_kernel<2>));
+    else SVNET_LDS_OPTIN(ok, BM * LDA + 512 * LDA + 6144, "binlinear_i8_fwd_kernel<4>", reinterpret_cast<const void*>(&binlinear_i8_fwd_kernel<4>));
+    if (!ok) return SVNET_E_LAUNCH;
 #define SVNET_BL_LAUNCH(NTW_)                                                                                                          \
     hipLaunchKernelGGL((binlinear_i8_fwd_kernel<NTW_>), grid, dim3(1024), lds, (hipStream_t)stream, x, ldx, beta, w_i8, scale, bias, M, (int)K, \
                        (int)O, Kp, y, reinterpret_cast<uint32_t*>(x_sign), reinterpret_cast<uint32_t*>(x_nz), reinterpret_cast<uint32_t*>(x_ste), col_sums)

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "../../include/svnet_hip.h"
 
 #define SVNET_WAVE 64
@@ -28,6 +30,29 @@ void svnet_set_error(const char* fmt, ...);
     } while (0)
 
 static inline int64_t svnet_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// More than 64 KiB of dynamic LDS needs an explicit opt-in, and hipFuncSetAttribute applies to the CURRENT device only: one bit per
+// device ordinal and call site (a process that touches a second GPU opts in there too), atomic (two host threads may race: the call is
+// idempotent), and the hipError_t is reported instead of dropped - the message of the launch failure that follows would not name it.
+static inline bool svnet_lds_optin(std::atomic<uint64_t>& done, const void* const* fns, int nf, int bytes, const char* name) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) {
+        const uint64_t bit = 1ull << (dev & 63);
+        if (done.load(std::memory_order_acquire) & bit) return true;
+        for (int i = 0; i < nf && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess) { done.fetch_or(bit, std::memory_order_release); return true; }
+    }
+    svnet_set_error("%s: cannot opt in to %d bytes of dynamic LDS on device %d: %s", name, bytes, dev, hipGetErrorString(e));
+    return false;
+}
+// SVNET_LDS_OPTIN(ok, bytes, name, kernel, ...): ok = false (and svnet_last_error set) when the opt-in failed on this device
+#define SVNET_LDS_OPTIN(ok, bytes, name, ...)                                                                 \
+    do {                                                                                                      \
+        static std::atomic<uint64_t> done_{0};                                                                \
+        const void* const fns_[] = {__VA_ARGS__};                                                             \
+        (ok) = svnet_lds_optin(done_, fns_, (int)(sizeof(fns_) / sizeof(fns_[0])), (int)(bytes), name);       \
+    } while (0)
 
 // Grid for memory-bound grid-stride kernels: enough blocks to fill 256 CUs x 8, capped.
 static inline unsigned svnet_grid(int64_t work_items, int block, int64_t cap = 256 * 16) {

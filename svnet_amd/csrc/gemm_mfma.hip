@@ -1320,11 +1320,9 @@ void launch_rows_v(const RowsArgs& a, hipStream_t st) {
     const int64_t cap = (a.K > KC) ? 4096 : 512 * 4;  // single-chunk B is loaded once per workgroup: keep workgroups persistent
     if (gx > cap) gx = cap;
     const size_t lds = (size_t)NT * 32 * LDS_STRIDE * sizeof(__bf16);
-    static bool attr_set = false;  // > 64 KiB of dynamic LDS needs an explicit opt-in (NT = 8: 68 KiB)
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_rows_kernel<NT, AVEC, DEEP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    bool ok = true;                // > 64 KiB of dynamic LDS needs an explicit opt-in (NT = 8: 68 KiB), per device
+    SVNET_LDS_OPTIN(ok, lds, "mfma_rows_kernel", reinterpret_cast<const void*>(&mfma_rows_kernel<NT, AVEC, DEEP>));
+    (void)ok;                      // (a failed opt-in is in svnet_last_error; the launch below then fails and is reported by the caller's check)
     hipLaunchKernelGGL((mfma_rows_kernel<NT, AVEC, DEEP>), dim3((unsigned)gx, (unsigned)ny), dim3(256), lds, st, a);
 }
 // the LDS-tiled kernel: many rows, aligned A rows with K % 4 == 0, pre-packed B whose padded column count covers whole 256-column groups
@@ -1338,14 +1336,10 @@ bool rows2_aligned(const RowsArgs& a) {
 bool launch_rows2(const RowsArgs& a, hipStream_t st) {
     if (!rows2_eligible(a)) return false;
     const size_t lds = (size_t)2 * R2_BUF_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_rows2_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_rows2_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_rows2_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_rows2_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    bool ok = true;
+    SVNET_LDS_OPTIN(ok, lds, "mfma_rows2_kernel", reinterpret_cast<const void*>(&mfma_rows2_kernel<1, true>), reinterpret_cast<const void*>(&mfma_rows2_kernel<3, true>),
+                    reinterpret_cast<const void*>(&mfma_rows2_kernel<1, false>), reinterpret_cast<const void*>(&mfma_rows2_kernel<3, false>));
+    (void)ok;
     const dim3 grid((unsigned)svnet_cdiv(a.M, R2_BM), (unsigned)svnet_cdiv(a.N, R2_BN));
     const bool av = rows2_aligned(a);
     if (a.b_piece) { if (av) hipLaunchKernelGGL((mfma_rows2_kernel<3, true>), grid, dim3(256), lds, st, a); else hipLaunchKernelGGL((mfma_rows2_kernel<3, false>), grid, dim3(256), lds, st, a); }
@@ -1355,13 +1349,10 @@ bool launch_rows2(const RowsArgs& a, hipStream_t st) {
 template <int NJ>
 void launch_rows3_nj(const RowsArgs& a, hipStream_t st) {
     const size_t lds = (size_t)R3_A_BYTES + 2 * (size_t)(64 * NJ) * R2_LDB * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_rows3_kernel<NJ, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_rows3_kernel<NJ, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_rows3_kernel<NJ, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    bool ok = true;
+    SVNET_LDS_OPTIN(ok, lds, "mfma_rows3_kernel", reinterpret_cast<const void*>(&mfma_rows3_kernel<NJ, 4>), reinterpret_cast<const void*>(&mfma_rows3_kernel<NJ, 2>),
+                    reinterpret_cast<const void*>(&mfma_rows3_kernel<NJ, 1>));
+    (void)ok;
     const dim3 grid((unsigned)svnet_cdiv(a.M, R2_BM), (unsigned)svnet_cdiv(a.N, 64 * NJ));
     const uintptr_t ap = reinterpret_cast<uintptr_t>(a.A);
     if ((ap & 15) == 0 && (a.lda & 3) == 0 && (a.K & 3) == 0) hipLaunchKernelGGL((mfma_rows3_kernel<NJ, 4>), grid, dim3(256), lds, st, a);
@@ -1423,12 +1414,10 @@ void launch_tn(TnArgs a, hipStream_t st) {
     const size_t lds = (size_t)(nsub - 1) * a.ptiles_per_block * NQ * 1024 * sizeof(float);
     a.lds_reduce = (nsub > 1 && ptiles == a.ptiles_per_block && lds <= 64 * 1024) ? 1 : 0;
     if (BMODE == 1) {
-        static bool attr_set = false;   // 8 KiB of static tables + up to 64 KiB of dynamic LDS: above the 64 KiB default
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_tn_tern_kernel<NQ, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_tn_tern_kernel<NQ, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-            attr_set = true;
-        }
+        bool ok = true;                 // 8 KiB of static tables + up to 64 KiB of dynamic LDS: above the 64 KiB default
+        SVNET_LDS_OPTIN(ok, 64 * 1024, "mfma_tn_tern_kernel", reinterpret_cast<const void*>(&mfma_tn_tern_kernel<NQ, false>),
+                        reinterpret_cast<const void*>(&mfma_tn_tern_kernel<NQ, true>));
+        (void)ok;
     }
     if (BMODE == 1 && a.n16)
         hipLaunchKernelGGL((mfma_tn_tern_kernel<NQ, true>), dim3((unsigned)gx, (unsigned)gy, (unsigned)gz), dim3(256), a.lds_reduce ? lds : 0, st, a);
@@ -1593,11 +1582,9 @@ extern "C" int svnet_edgeblock_wgrad_f32(const int16_t* n16, const uint8_t* slot
         int64_t rpb = svnet_cdiv(svnet_cdiv(E, target), 64) * 64;
         if (rpb < 256) rpb = 256;
         a.rows_per_block = rpb;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_tn_aff2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)A2_LDS_BYTES);
-            attr_set = true;
-        }
+        bool ok = true;
+        SVNET_LDS_OPTIN(ok, A2_LDS_BYTES, "mfma_tn_aff2_kernel", reinterpret_cast<const void*>(&mfma_tn_aff2_kernel));
+        if (!ok) return SVNET_E_LAUNCH;
         hipLaunchKernelGGL(mfma_tn_aff2_kernel, dim3((unsigned)svnet_cdiv(E, rpb)), dim3(512), A2_LDS_BYTES, st, a);
         SVNET_CHECK_LAUNCH("mfma_tn_aff2_kernel");
         return SVNET_OK;

@@ -1070,8 +1070,9 @@ void launch_main(const float* xT, const float* xx, int64_t B, int N, int C, int 
     if constexpr (T == 16 && Q == 4) {
         if (mf8) {                            // 32 queries per workgroup on the f32 matrix cores (channel-major table)
             constexpr size_t lds = (size_t)2 * 8 * (64 * T + 16) * sizeof(float);
-            static const int once = hipFuncSetAttribute((const void*)knn_mf8_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)once;
+            bool ok = true;                   // (per device; a failed opt-in is in svnet_last_error and the launch below fails)
+            SVNET_LDS_OPTIN(ok, lds, "knn_mf8_kernel", (const void*)knn_mf8_kernel<T>);
+            (void)ok;
             dim3 g8((unsigned)svnet_cdiv(N, 32), (unsigned)B);
             int per8 = 0;
             if ((B & 7) == 0) { per8 = (int)g8.x; g8 = dim3((unsigned)(g8.x * B), 1u); }

@@ -156,8 +156,9 @@ __global__ __launch_bounds__(512, 2) void vlinear_stats_kernel(VlinArgs a) {
 template <int KP>
 int vl_launch(const VlinArgs& a, hipStream_t st) {
     const size_t lds = (size_t)(3 * VL_ROWS + 32 * ((a.O + 31) / 32)) * (KP + 8) * 2;
-    static const int once = hipFuncSetAttribute((const void*)vlinear_stats_kernel<KP>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    (void)once;
+    bool ok = true;
+    SVNET_LDS_OPTIN(ok, 128 * 1024, "vlinear_stats_kernel", (const void*)vlinear_stats_kernel<KP>);
+    if (!ok) return SVNET_E_LAUNCH;
     static const int cus = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
     const int per_cu = lds <= 80 * 1024 ? 2 : 1;                               // (160 KB of LDS per CU)
     int grid = cus * per_cu;                                                    // resident workgroups walk the tiles

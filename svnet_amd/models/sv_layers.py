@@ -336,7 +336,7 @@ class SVBlock(nn.Module):
             return _ops.V2SCat.apply(s, v, lin.weight, lin.scale if lin.bw else None, self.training)
         return torch.cat([s, self.v2s(v)], dim=-1)
 
-    def _cat_and_gate(self, s, v, side=None):
+    def _cat_and_gate(self, s, v):
         """(cat[s, Vector2Scalar(v)], gate) with s consumed ONCE: the concatenation op also returns the per-cloud mean of s the gate MLP
         starts from (sv_layers.py:179), so that its backward writes dL/ds once (the cat gradient's s columns + the mean's broadcast)
         instead of autograd adding a broadcast tensor and a strided slice.  None when the pieces are not fusable."""
@@ -346,12 +346,6 @@ class SVBlock(nn.Module):
         if not (self._v2s_cat_fusable(s, v) and s.dim() >= 3 and s.shape[-1] >= 128 and self.gate[0].out_features <= 256
                 and self.gate[2].out_features <= 256):
             return None
-        if side is not None:
-            # the gate's chain (mean of s over each cloud -> MLP) on the SIDE stream, behind linear2's product: its only consumer is the
-            # VectorBN there, and on the main stream it stood in front of linear1 (34 + 29 us of latency-bound launches at conv5)
-            cat, s_mean = _ops.V2SCat.apply(s, v, lin.weight, lin.scale if lin.bw else None, self.training, s.shape[0], True)
-            with torch.cuda.stream(side):
-                return cat, _ops.GateMLP.apply(s_mean, self.gate[0].weight, self.gate[2].weight)
         cat, s_mean = _ops.V2SCat.apply(s, v, lin.weight, lin.scale if lin.bw else None, self.training, s.shape[0])
         return cat, _ops.GateMLP.apply(s_mean, self.gate[0].weight, self.gate[2].weight)
 
@@ -373,13 +367,12 @@ class SVBlock(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 v_lin = self.linear2(v, vstats=True)
-            fused = self._cat_and_gate(s, v, side if config.GATE_ON_SIDE else None)
+            fused = self._cat_and_gate(s, v)
             if fused is not None:
                 s_cat, v_scale = fused
             else:
                 v_scale = self._gate(s)
-            if not (config.GATE_ON_SIDE and fused is not None):
-                side.wait_stream(main)                   # (the gate came from the main stream)
+            side.wait_stream(main)                       # (the gate came from the main stream)
             with torch.cuda.stream(side):
                 v_out = self.bn2(v_lin, gate=v_scale)
             s_out = self.linear1(s_cat if fused is not None else self._cat_s_v2s(s, v))

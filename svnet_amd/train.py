@@ -53,7 +53,9 @@ class TrainStep:
         """config.DEFER_WGRAD hands autograd parameter gradients that the side stream has not written yet; that is sound only while
         autograd merely ADOPTS them as .grad (never reads them on the main stream): every parameter used by ONE module only (a shared
         one gets two gradients, added on the main stream), .grad None at backward (bucket.begin()), no tensor / post-accumulate hooks
-        (they run on the main stream).  Anything else falls back to the per-layer join."""
+        (they run on the main stream).  Anything else falls back to the per-layer join.  What this static check cannot see - one
+        module applied twice in a forward, a parameter read by two Functions - is counted at run time: _ops.DEFERRED.first_use() sends the
+        second backward of the same weights down the joined schedule."""
         seen = set()
         for _, p in self.model.named_parameters(remove_duplicate=False):
             if id(p) in seen:
@@ -251,8 +253,15 @@ class _FlatOptimizer:
         raise NotImplementedError
 
     def capture(self):
-        """Call after the model has run at least once (the packed forms exist) and the parameters live in their flat buffer."""
+        """Call after the model has run at least once (the packed forms exist) and the parameters live in their flat buffer.
+        The warm-up and the capture launch the REAL update kernel on the live buffers with neutral scalars (lr 0, betas 1): every
+        product with a finite gradient is then exactly "keep the value", but 0 * inf = NaN would poison the moments - so a non-finite
+        gradient bucket is refused here (one host sync, at capture time only).  The graph bakes the buffers' addresses in:
+        they are recorded, and a step after they moved (re-homed parameters, a load that re-allocated the state) raises."""
         dev = self.p.device
+        if not bool(torch.isfinite(self.g).all()):
+            raise FloatingPointError("FlatOptimizer.capture(): the gradient bucket holds inf / NaN - capture after a finite backward "
+                                     "(the neutral warm-up step would write NaN into the optimizer state)")
         self._hyper = torch.zeros(8, dtype=torch.float32, device=dev)
         # (a ring of pinned staging slots: the host runs ahead of the device, so a slot is rewritten only after the copy that read it last)
         self._hyper_ring = [(torch.zeros(8, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(16)]
@@ -287,7 +296,14 @@ class _FlatOptimizer:
         with torch.cuda.graph(graph, stream=stream):
             self._keys = record()
         self._graph = graph
+        self._captured_ptrs = self._buffer_ptrs()
         return self
+
+    def _buffer_ptrs(self):
+        return tuple(t.data_ptr() for t in self._state_tensors())
+
+    def _state_tensors(self):
+        raise NotImplementedError
 
     def _put_hyper(self, vals):
         host, ev = self._hyper_ring[self._hyper_slot]
@@ -298,6 +314,9 @@ class _FlatOptimizer:
         ev.record()
 
     def _step_captured(self):
+        if self._buffer_ptrs() != self._captured_ptrs:
+            raise RuntimeError("FlatOptimizer: the parameter / gradient / state buffers moved since capture() (re-homed parameters or a "
+                               "re-allocated state): the captured graph would update the old memory - call capture() again")
         self._put_hyper(self._hyper_values())
         self._graph.replay()
         if set(_ops.PLANES.entries) <= set(self._keys):
@@ -343,6 +362,9 @@ class FlatAdam(_FlatOptimizer):
 
     def _neutral_hyper(self):
         return [0.0, 1.0, 1.0, self.eps, 0.0, 1.0, 1.0]      # lr 0, betas 1: parameters and both moments keep their values
+
+    def _state_tensors(self):
+        return (self.p, self.g, self.m, self.v)
 
     def _hyper_values(self):
         bc1 = 1.0 - self.b1 ** self.steps
@@ -393,6 +415,9 @@ class FlatSGD(_FlatOptimizer):
 
     def _neutral_hyper(self):
         return [0.0, 0.0, 0.0, 1.0]
+
+    def _state_tensors(self):
+        return (self.p, self.g, self.buf)
 
     def _hyper_values(self):
         return [self.lr, self.momentum, self.wd, 1.0 if self.steps == 1 else 0.0]

@@ -96,9 +96,10 @@ TRAIN_CASES = [c for c in C.MODEL_CASES if c[0].endswith("_small") and c[0] != "
     ("dgcnn_bin_n1024", "sv_dgcnn_cls", True, 8, 1024, 20),
     # BASELINE config 5's shape (N = 2048, k = 40; sv_dgcnn_partseg.py:80-128): the k = 40 backward instantiations -
     # edgeblock_bwd_kernel<0,8,48> / <0,4,44> / <0,2,44>, the N = 2048 reverse lists, the vector-form k-NN with its merged selection,
-    # the rows head on 2144 columns - chained against the oracle in TRAIN mode (rounds 1-4 stopped at N = 128 there).  B = 4: the
-    # per-cloud blocks conv6 / conv7 normalise over B rows, so B = 2 would be the ill-conditioned pseg_fp_small again
-    ("pseg_bin_n2048", "sv_dgcnn_pseg", True, 4, 2048, 40),
+    # the rows head on 2144 columns - chained against the oracle in TRAIN mode (rounds 1-4 stopped at N = 128 there).  B = 2, like the
+    # STRICT pseg_bin_small (the binary model's per-cloud blocks are well conditioned at two rows; only the fp twin is not): the float64
+    # oracle step on E = 163 840 edges of 272 columns is what bounds the size - B = 4 ran past seven minutes on the GPU box's host
+    ("pseg_bin_n2048", "sv_dgcnn_pseg", True, 2, 2048, 40),
 ]
 # cases held to the north-star tolerance itself (1e-3) on every tensor, whatever the yard-sticks say
 STRICT = ("dgcnn_bin_small", "dgcnn_fp_small", "pseg_bin_small", "dgcnn_bin_b16", "dgcnn_bin_b16b", "dgcnn_bin_b8", "dgcnn_fp_b16",
@@ -249,9 +250,15 @@ def test_fused_edge_block_backward_matches_exact_oracle(shape, hip_device):
     s, v = C.sv_pair(tag + "/pt", (B, N), Cs, Cv, 1.0)
     s = torch.round(s * 4) / 4                         # discrete scalars like a binary net's: exact zeros / ties
     sd, vd = s.to(hip_device).requires_grad_(True), v.to(hip_device).requires_grad_(True)
-    edges = get_graph_feature_sv((sd, vd), k=k)
-    idx = edges.idx.cpu()
-    os_, ov = svpool(blk(edges))
+    # at config 5's size the layer takes 163 840 x 272 sign decisions and ~10^5 arg-max selections: a handful are knife edges of rounding
+    # (|s_v + beta| within an ulp of zero; seen: ONE flipped sign = one popcount off by 2 = 2.7e-2 of the output's range), so there the HIP
+    # run's decisions are replayed into the oracle and every one it would have taken differently is certified (tests/decisions.py) -
+    # the element-wise bound stays 1e-3.  The headline-size shapes keep running free.
+    replay = N > 1024
+    with (tapped() if replay else contextlib.nullcontext()) as tap:
+        edges = get_graph_feature_sv((sd, vd), k=k)
+        idx = edges.idx.cpu()
+        os_, ov = svpool(blk(edges))
     rs, rv = C.t(tag + "/rs", tuple(os_.shape)), C.t(tag + "/rv", tuple(ov.shape))
     ((os_ * rs.to(hip_device)).sum() + (ov * rv.to(hip_device)).sum()).backward()
     got = {"out0": os_.detach().cpu().numpy(), "out1": ov.detach().cpu().numpy(), "dx0": sd.grad.cpu().numpy(), "dx1": vd.grad.cpu().numpy()}
@@ -260,13 +267,19 @@ def test_fused_edge_block_backward_matches_exact_oracle(shape, hip_device):
     P = {"m." + n: t.clone().requires_grad_(t.is_floating_point()) for n, t in params.items()}
     so, vo = s.clone().requires_grad_(True), v.clone().requires_grad_(True)
     ctx = sv_ref.Ctx(train=True, exact_ste=True)
+    if replay:
+        dec = decisions_of(tap, model=blk)
+        dec.knn = []                                   # (the graph is handed over below, not decided by the oracle)
+        dec.acts = {"m." + n: a for n, a in dec.acts.items()}
+        ctx.decisions = dec
     glob = (idx + torch.arange(B).view(B, 1, 1) * N).reshape(-1)
-    oo, ovv = sv_ref.svpool(sv_ref.svblock(sv_ref.graph_feature_sv((so, vo), k=k, idx=glob), P, "m", True, ctx))
+    oo, ovv = sv_ref.svpool(sv_ref.svblock(sv_ref.graph_feature_sv((so, vo), k=k, idx=glob, ctx=ctx), P, "m", True, ctx), ctx=ctx)
+    cert = ctx.decisions.check() if replay else None
     ((oo * rs).sum() + (ovv * rv).sum()).backward()
     ref = {"out0": oo.detach().numpy(), "out1": ovv.detach().numpy(), "dx0": so.grad.numpy(), "dx1": vo.grad.numpy()}
     ref.update({"d:" + n: P["m." + n].grad.numpy() for n, _ in blk.named_parameters()})
     report = sorted(((H.max_rel_err(got[kn], ref[kn]), kn) for kn in ref), reverse=True)
     os.makedirs(OUT, exist_ok=True)
     with open(os.path.join(OUT, "fused_block_errors_%s.json" % tag), "w") as f:
-        json.dump([(float(e), n) for e, n in report], f, indent=0)
+        json.dump({"errors": [(float(e), n) for e, n in report], "replayed_decisions": cert}, f, indent=0)
     compare_case(got, ref, GRAD_RTOL, "fused edge block vs exact oracle (%s)" % tag)

@@ -219,3 +219,17 @@ def test_bench_parent_fails_when_a_rank_fails_and_refuses_a_wrong_world_size():
     rc, lines, err = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--selftest-cpu"],
                                 env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert rc == 2 and not lines and "WORLD_SIZE" in err
+
+
+def test_a_second_backward_of_the_same_weights_is_not_deferred():
+    """a module applied twice in one forward hands autograd TWO gradients of the same weights, which it adds on the main
+    stream - the second must not be an unwritten side-stream tensor.  _Deferred.first_use() is the run-time consumer count (CPU logic)."""
+    from svnet_amd import _ops
+    d = _ops._Deferred()
+    a, b, c = torch.zeros(3), torch.zeros(3), torch.zeros(3)
+    assert d.first_use(a, b)
+    assert d.first_use(c, None)
+    assert not d.first_use(a)              # the same weights again in this backward: joined schedule
+    assert not d.first_use(c, torch.zeros(2))
+    d.join(torch.device("cpu"))            # (nothing kept: no stream is touched) - the next backward starts counting afresh
+    assert d.first_use(a, b, c)
