@@ -127,15 +127,33 @@ def cpu_info():
     return model, (len(cores) or (os.cpu_count() or 1))
 
 
-def cpu_baseline(wl, sample_b=4, timed=3):
-    """The oracle (CPU restatement of the reference, kind "port") timed on this box's host cores on a bounded sample of
-    the same workload (same model, N, k; B=sample_b): SURVEY §8(d) protocol, 1 warm-up + 3 timed, median, both
-    fwd+cal_loss+bwd (train) and forward only (eval, no_grad)."""
+def cpu_share():
+    """Host cores this process may really use: affinity mask and cgroup CPU quota.  A 1-GPU box of the pool shows 256 logical CPUs and
+    a quota of 16 cores: torch's default 128 threads ran the oracle 2.7x SLOWER there than 16 (profiles/r05_cpu_threads.txt)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(wl, sample_b=None, timed=3, threads=None):
+    """The oracle (CPU restatement of the reference, kind "port") timed on this box's host cores on the SAME workload (same model,
+    N, k and - round 5 - the same B; `sample_b` bounds it for the slower workloads): SURVEY §8(d) / BASELINE.md §3 protocol, 1 warm-up +
+    3 timed, median, both fwd+cal_loss+bwd (train) and forward only (eval, no_grad).  Threads = the cores this process may use
+    (cpu_share(): the cgroup quota), not the logical CPU count."""
     import torch
     from svnet_amd import synth
     from oracle import params as oparams, sv_ref
     model, phys = cpu_info()
-    threads = torch.get_num_threads()
+    if sample_b is None:
+        sample_b = wl["B"]
+    share = cpu_share()
+    threads = int(threads) if threads else min(torch.get_num_threads(), share)
+    torch.set_num_threads(threads)
     name, binary, N, k = wl["model"], wl["binary"], wl["N"], wl["k"]
     P = oparams.synthetic_params(name, binary=binary, seed=1234, requires_grad=True)
     x = torch.from_numpy(synth.cloud_batch(1234, 0, 0, sample_b, N))
@@ -172,10 +190,11 @@ def cpu_baseline(wl, sample_b=4, timed=3):
 
     t_train, t_eval = median_time(train_once), median_time(eval_once)
     return {"value": round(sample_b / t_train, 4), "unit": "point-clouds/sec", "cores": threads, "kind": "port",
-            "forward_only_value": round(sample_b / t_eval, 4), "cpu_model": model, "physical_cores": phys,
-            "sample": "oracle (torch CPU ops, %d threads) of %s at B=%d N=%d k=%d: median of %d after 1 warm-up; "
+            "forward_only_value": round(sample_b / t_eval, 4), "cpu_model": model, "physical_cores": phys, "cpu_share": share,
+            "sample": "oracle (torch CPU ops, %d threads = this process's CPU share of %d cores) of %s at B=%d N=%d k=%d (the bench's own batch: "
+                      "profiles/r05_cpu_baseline_table.txt shows the per-cloud rate flat in B): median of %d after 1 warm-up; "
                       "fwd+loss+bwd %.2f s, forward only (eval, no_grad) %.2f s per batch"
-                      % (threads, wl["name"], sample_b, N, k, timed, t_train, t_eval)}
+                      % (threads, share, wl["name"], sample_b, N, k, timed, t_train, t_eval)}
 
 
 # ----------------------------------------------------------------------------- roofline legs
@@ -783,7 +802,8 @@ def rank_main(args):
         if others:
             out["other_workloads"] = others
         if world == 1 and not args.no_cpu_baseline and not selftest:
-            out["cpu_baseline"] = cpu_baseline(wl, sample_b=4 if wl["model"] != "sv_dgcnn_pseg" else 2)
+            # the headline workload at its own B = 32; the secondary workloads on a bounded sample (--workload runs only)
+            out["cpu_baseline"] = cpu_baseline(wl, sample_b=None if args.workload == "dgcnn_cls" else (8 if wl["model"] != "sv_dgcnn_pseg" else 2))
         print(json.dumps(out))
         sys.stdout.flush()
     if collective:

@@ -47,7 +47,7 @@ int svnet_slices_sum_f64(double* buf, int64_t L, void* stream);
  * changes its required length (200: sliced accumulators, SVNET_SLICED_LEN; 400: this header; 401: the totals of a sliced accumulator are
  * written by its consumer, svnet_slices_sum_*; 402: GX of svnet_v2s_bwd_*, gw of svnet_xyzblock_bwd_f32 and col_sum of svnet_gemm_f32 are sliced accumulators; 403: svnet_binweight_grad_f32 takes sliced inputs).  svnet_version() returns the value the
  * library was BUILT with: a caller compiled against another header must refuse to run (svnet_amd/_lib.py does).                   */
-#define SVNET_ABI_VERSION 407
+#define SVNET_ABI_VERSION 408
 int svnet_version(void);
 const char* svnet_last_error(void);
 
@@ -468,6 +468,28 @@ int svnet_bn_pool_bwd_f32(const float* gmax, const float* gmean, int64_t g_ld, c
                           int64_t inner, int act, float slope, int train_stats, float* red, float* dy, void* stream);   /* out[o*out_ld + i]; argmax [outer,inner] */
 int svnet_pool_bwd_f32(const float* g, const int32_t* argmax, int64_t outer, int64_t R, int64_t inner, int mode,
                        float* dx, void* stream);
+/* The tail of the classifier's vector path as one pass over linear2's product v [B*N, 3, C] (C <= 192): VectorBN + gate
+ * (sv_layers.py:86-102,193-194) -> Vector2Scalar of svfuse (sv_layers.py:111-129,206-220; w_eff [3, C] = scale * sign(W)) -> [max | mean]
+ * over each cloud's N points (sv_dgcnn_cls.py:70-74) - neither VectorBN's output nor the [B*N, 3C] scalars are written.
+ * sums != NULL (training): the sliced fp64 accumulator svnet_colstats_f64(v, B*N, C, kind 1) filled; the batch statistics are
+ * finalised inside (mean / invstd [C] written, running statistics and *nbt updated as svnet_vbn_fwd_stats_f32 does).  sums == NULL
+ * (eval): mean / invstd are INPUTS (svnet_bn_eval_stats_f32).  gate [B, C] or NULL.  out_max / out_mean [B, 3C] rows of stride out_ld,
+ * argmax [B, 3C] int32 (point index in the cloud, first index on ties); workspace = svnet_vtail_workspace_bytes(B, N, C) bytes.
+ * The maxima equal pooling the layer-wise chain's output; the means add their partial sums in a fixed order (bit-reproducible).   */
+size_t svnet_vtail_workspace_bytes(int64_t B, int64_t N, int64_t C);
+int svnet_vtail_fwd_f32(const float* v, const double* sums, float eps, float momentum, float* mean, float* invstd,
+                        float* running_mean, float* running_var, long long* nbt, const float* gamma, const float* beta,
+                        const float* gate, const float* w_eff, int64_t B, int64_t N, int64_t C, float* out_max, float* out_mean,
+                        int64_t out_ld, int32_t* argmax, void* workspace, size_t workspace_bytes, void* stream);
+/* Its backward up to VectorBN's batch sums, from the POOLED gradients (gmax / gmean: rows of stride g_ld): the gradient of the scalars,
+ * (point == argmax ? gmax : 0) + gmean / N, is formed on the fly, Vector2Scalar's backward runs in registers.  Outputs: g5 [B*N, 3, C] =
+ * dL/d(VectorBN's output), to be handed to svnet_vbn_bwd_apply_f32 as its `g` together with `red`; red = SLICED accumulator of 2C floats
+ * (SVNET_SLICED_LEN(2C), zero-filled; the apply pass adds the slices up and leaves [dbeta | dgamma]); dgate [B, C] (zero-filled, += ; may
+ * be NULL when gate is); GX = sliced accumulator of 3C floats: dL/d(w_eff) as [3][C] (svnet_binweight_grad_f32 with gx_sliced).        */
+int svnet_vtail_bwd_f32(const float* v, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                        const float* gate, const float* w_eff, const float* gmax, const float* gmean, int64_t g_ld,
+                        const int32_t* argmax, int64_t B, int64_t N, int64_t C, float* red, float* dgate, float* GX, float* g5,
+                        void* stream);
 /* dx[o,r,i] = add[(o*R + r)*add_ld + i] + gmean[o,i] / R: the backward of a mean over r (sv_layers.py:179: the gate's pooled input) added to
  * another gradient of the same tensor that arrives as rows of stride add_ld (the s columns of the gradient of cat[s, Vector2Scalar(v)],
  * sv_layers.py:187-188) - one pass instead of a broadcast pass and a strided elementwise add.                                       */

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVNET_DIAG_LIB") or os.path.join(_HERE, "libsvnet_hip.so")    # (SVNET_DIAG_LIB: an ablation build, tools/ only)
 _lib = None
-ABI_VERSION = 407       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
+ABI_VERSION = 408       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
 
 c_p = ctypes.c_void_p
 c_i64 = ctypes.c_int64
@@ -196,6 +196,9 @@ SIGNATURES = {
     "svnet_pool_bwd_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_int, c_p, c_p]),
     "svnet_pool_mean_bwd_add_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
     "svnet_pool_maxmean_bwd_f32": (c_int, [c_p, c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p]),
+    "svnet_vtail_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
+    "svnet_vtail_fwd_f32": (c_int, [c_p, c_p, c_f, c_f] + [c_p] * 9 + [c_i64] * 3 + [c_p, c_p, c_i64, c_p, c_p, c_sz, c_p]),
+    "svnet_vtail_bwd_f32": (c_int, [c_p] * 9 + [c_i64, c_p] + [c_i64] * 3 + [c_p] * 5),
     "svnet_act_fwd_f32": (c_int, [c_p, c_i64, c_int, c_p, c_p]),
     "svnet_act_bwd_f32": (c_int, [c_p, c_p, c_i64, c_int, c_p, c_p]),
     "svnet_vlinear_stats_f32": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_p, c_p]),

@@ -1193,6 +1193,114 @@ class GlobalMaxMeanPoolBN(torch.autograd.Function):
         return dy, db, red[Ca:2 * Ca], red[:Ca], None, None, None, None, None, None, None, None
 
 
+class GlobalMaxMeanPoolBNV(torch.autograd.Function):
+    """The classifier's whole tail behind conv5's two products (sv_dgcnn_cls.py:68-74), from what they leave in HBM:
+        y     [B,N,Ca]    linear1's output BEFORE bn1 + LeakyReLU          (as GlobalMaxMeanPoolBN)
+        v_lin [B,N,3,C]   linear2's output BEFORE VectorBN and the gate
+    out [B, 2*(Ca+3C)] = [max a | max b | mean a | mean b] over the points, a = act(bn1(y)), b = svfuse's Vector2Scalar of
+    VectorBN(v_lin) * gate.  The scalar half is GlobalMaxMeanPoolBN's; the vector half is ONE pass over v_lin each way
+    (csrc/vtail.hip): VectorBN's output v5, the scalars s_v [B,N,3C] and their gradient are never written - layer by layer the half
+    was three passes forward (VectorBN, Vector2Scalar, pooling: 335 MB) and three backward (401 MB before VectorBN's apply pass)."""
+
+    @staticmethod
+    def supported(B, N, Ca, C):
+        return C <= 192 and GlobalMaxMeanPoolBN.supported(B, N, Ca)
+
+    @staticmethod
+    def forward(ctx, y, v_lin, gate, g1, b1, rm1, rv1, g2, b2, rm2, rv2, Wz, scz, training, act, slope, nbt1=None, nbt2=None,
+                eps=BN_EPS, momentum=BN_MOMENTUM):
+        global _FUSED_VSTATS
+        _hip(y, v_lin, gate, g1, b1, g2, b2, Wz, scz)
+        y, v_lin = _f32c(y), _f32c(v_lin)
+        B, N, Ca = y.shape
+        C = v_lin.shape[-1]
+        Cb, P = 3 * C, B * N
+        Ct = Ca + Cb
+        L = _lib.lib()
+        dev = y.device
+        y2, v3 = y.reshape(P, Ca), v_lin.reshape(P, 3, C)
+        gate2 = None if gate is None else _f32c(gate).reshape(B, C)
+        W_in, Wzc = Wz, _f32c(Wz)
+        if scz is not None:
+            sczf = _f32c(scz).view(-1)
+            w_eff = _binweight(W_in, scz)["w_eff"]
+        else:
+            sczf, w_eff = None, Wzc
+        mean1, invstd1 = _batch_stats(y2, P, Ca, 0, rm1, rv1, training, momentum, eps, nbt1)
+        out = torch.empty((B, 2 * Ct), dtype=torch.float32, device=dev)
+        mean2 = torch.empty((C,), dtype=torch.float32, device=dev)
+        invstd2 = torch.empty((C,), dtype=torch.float32, device=dev)
+        arg_b = torch.empty((B, Cb), dtype=torch.int32, device=dev)
+        nbw = L.svnet_vtail_workspace_bytes(B, N, C)
+        wsb = torch.empty((nbw,), dtype=torch.uint8, device=dev)
+        rec, _FUSED_VSTATS = _FUSED_VSTATS, None
+        main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+        side.wait_stream(main)                                          # (the gate and the statistics buffers come from this stream)
+        with torch.cuda.stream(side):                                   # the vector half beside the scalar half
+            sums = None
+            if training:
+                if (rec is not None and rec[0].data_ptr() == v3.data_ptr() and rec[0].numel() == v3.numel() and rec[0]._version == rec[1]):
+                    sums = rec[2]                                       # the producing product's sums (csrc/vlinear.hip)
+                else:
+                    sums = _zeros((_sliced_len(2 * C),), torch.float64, dev)
+                    call("svnet_colstats_f64", _p(v3), P, C, 1, _p(sums), _stream())
+            else:
+                call("svnet_bn_eval_stats_f32", _p(rm2), _p(rv2), C, eps, _p(mean2), _p(invstd2), _stream())
+            call("svnet_vtail_fwd_f32", _p(v3), _p(sums), eps, momentum, _p(mean2), _p(invstd2), _p(rm2) if training else None,
+                 _p(rv2) if training else None, _p(nbt2) if training else None, _p(g2), _p(b2), _p(gate2), _p(w_eff), B, N, C,
+                 _p(out[:, Ca:]), _p(out[:, Ct + Ca:]), 2 * Ct, _p(arg_b), _p(wsb), nbw, _stream())
+        nb = L.svnet_pool_workspace_bytes(B, N, Ca, 0) + L.svnet_pool_workspace_bytes(B, N, Ca, 1)
+        ws = torch.empty((nb,), dtype=torch.uint8, device=dev)
+        arg_a = torch.empty((B, Ca), dtype=torch.int32, device=dev)
+        call("svnet_bn_pool_fwd_f32", _p(y2), _p(mean1), _p(invstd1), _p(g1), _p(b1), B, N, Ca, act, slope, _p(out), _p(out[:, Ct:]),
+             2 * Ct, _p(arg_a), _p(ws), nb, _stream())
+        main.wait_stream(side)
+        ctx.save_for_backward(y2, mean1, invstd1, g1, b1, arg_a, arg_b, v3, mean2, invstd2, g2, b2, gate2, w_eff, Wzc, sczf)
+        if TAP is not None:
+            TAP["pools"].append(torch.cat([arg_a, arg_b], dim=1))
+            if "acts" in TAP and act in (1, 2):
+                TAP["acts"].append((g1.data_ptr(), ((y2 - mean1) * invstd1 * g1 + b1) > 0))
+        ctx.meta = (B, N, Ca, C, act, slope, bool(training), v_lin.shape, None if gate is None else gate.shape,
+                    None if scz is None else scz.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        y2, mean1, invstd1, g1, b1, arg_a, arg_b, v3, mean2, invstd2, g2, b2, gate2, w_eff, Wzc, sczf = ctx.saved_tensors
+        B, N, Ca, C, act, slope, training, vshape, gshape, scshape = ctx.meta
+        Cb, P = 3 * C, B * N
+        Ct = Ca + Cb
+        g = _f32c(g)
+        dev = g.device
+        F = torch.float32
+        dy = torch.empty((B, N, Ca), dtype=F, device=dev) if ctx.needs_input_grad[0] else None
+        dv = torch.empty((P, 3, C), dtype=F, device=dev)
+        g5 = torch.empty((P, 3, C), dtype=F, device=dev)
+        red1, red2, dgate, gxb = _zeros_pool(dev, ((_sliced_len(2 * Ca),), F), ((_sliced_len(2 * C),), F), ((B, C), F), ((_sliced_len(3 * C),), F))
+        main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            call("svnet_vtail_bwd_f32", _p(v3), _p(mean2), _p(invstd2), _p(g2), _p(b2), _p(gate2), _p(w_eff), _p(g[:, Ca:]), _p(g[:, Ct + Ca:]),
+                 2 * Ct, _p(arg_b), B, N, C, _p(red2), _p(dgate) if gate2 is not None else None, _p(gxb), _p(g5), _stream())
+            call("svnet_vbn_bwd_apply_f32", _p(g5), _p(v3), _p(mean2), _p(invstd2), _p(g2), _p(b2), _p(gate2), _p(red2), N, P, C,
+                 int(training), _p(dv), _stream())
+            if sczf is not None:
+                dWz, dscz = _binweight_grad(gxb, Wzc, sczf, 3, C, training, gx_sliced=True)
+                dscz = dscz.view(scshape)
+            else:
+                call("svnet_slices_sum_f32", _p(gxb), 3 * C, _stream())
+                dWz, dscz = gxb[:3 * C].view(3, C), None
+        call("svnet_bn_pool_bwd_f32", _p(g), _p(g[:, Ct:]), 2 * Ct, _p(arg_a), _p(y2), _p(mean1), _p(invstd1), _p(g1), _p(b1), B, N, Ca,
+             act, slope, int(training), _p(red1), _p(dy), _stream())
+        main.wait_stream(side)
+        for t in (dv, g5, dWz, dscz):
+            if t is not None:
+                t.record_stream(main)
+        # forward args: y, v_lin, gate, g1, b1, rm1, rv1, g2, b2, rm2, rv2, Wz, scz, training, act, slope, nbt1, nbt2, eps, momentum
+        return (dy, dv.view(vshape), dgate.view(gshape) if gate2 is not None else None, red1[Ca:2 * Ca], red1[:Ca], None, None,
+                red2[C:2 * C], red2[:C], None, None, dWz, dscz, None, None, None, None, None, None, None)
+
+
 class Act(torch.autograd.Function):
     """kind 1 relu, 2 sigmoid, 3 leaky-relu(0.2) (sv_layers.py:156-161)."""
 

@@ -29,6 +29,10 @@ DW_BESIDE = False      # measured: +0.12 ms per step on sv_dgcnn_cls B=32 (5.75 
 # Classifier: conv5's BatchNorm + LeakyReLU inside the global [max | mean] pooling pass (no activated [B,N,512] tensor, no gradient of it).
 FUSE_BN_POOL = True
 
+# ... and conv5's VectorBN + gate, svfuse's Vector2Scalar and the pooling of its half as ONE pass over linear2's product each way
+# (csrc/vtail.hip, _ops.GlobalMaxMeanPoolBNV): VectorBN's output, the [B,N,510] scalars and their gradient are never written.
+FUSE_VTAIL = True
+
 # SVBlock on rows: cat[s, Vector2Scalar(v)] written in place by the Vector2Scalar kernel (no intermediate, no cat pass).
 FUSE_V2S_CAT = True
 

@@ -54,6 +54,19 @@ class SV_DGCNN_CLS(nn.Module):
         if (config.FUSE_BN_POOL and x5[0].is_cuda and x5[0].dim() == 3 and bn.track_running_stats
                 and _ops.GlobalMaxMeanPoolBN.supported(x5[0].shape[0], x5[0].shape[1], self.conv5.linear1.out_features)):
             # bn1 + LeakyReLU of conv5 run inside the pooling pass (the activated [B,N,512] tensor and its gradient are never written)
+            bn2, fz = self.conv5.bn2.bn, self.svfuse.v2s.linear
+            if (config.FUSE_VTAIL and not self.svfuse.trans_back and self.conv5._default_bn() and bn2.affine and fz.weight.shape[0] == 3
+                    and bn.training == bn2.training
+                    and _ops.GlobalMaxMeanPoolBNV.supported(x5[0].shape[0], x5[0].shape[1], self.conv5.linear1.out_features, fz.weight.shape[1])):
+                # ... and so do VectorBN, the gate, svfuse's Vector2Scalar and the pooling of ITS half, in one pass over linear2's product
+                y5, v_lin, gate = self.conv5.forward_pretail(x5)
+                pooled = _ops.GlobalMaxMeanPoolBNV.apply(
+                    y5, v_lin, gate, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn2.weight, bn2.bias, bn2.running_mean,
+                    bn2.running_var, fz.weight, fz.scale if fz.bw else None, bn.training, _ACT_LEAKY, self.conv5.relu.negative_slope,
+                    bn.num_batches_tracked if bn.training else None, bn2.num_batches_tracked if bn2.training else None, bn.eps, _bn_momentum(bn))
+                h = self.dp1(linear_bn_act(self.linear1, self.bn1, pooled, _ACT_LEAKY, 0.2))
+                h = self.dp2(linear_bn_act(self.linear2, self.bn2, h, _ACT_LEAKY, 0.2))
+                return _ops.FpLinear.apply(h, self.linear3.weight, self.linear3.bias)
             y5, v5 = self.conv5.forward_prebn(x5)
             sv5 = self.svfuse.v2s(v5)
             nbt = bn.num_batches_tracked if bn.training else None

@@ -354,7 +354,13 @@ class SVBlock(nn.Module):
         does next (the classifier's global pooling, _ops.GlobalMaxMeanPoolBN).  Rows path only."""
         return self._forward_rows(x, prebn=True)
 
-    def _forward_rows(self, x, prebn=False):
+    def forward_pretail(self, x):
+        """(y, v_lin, gate): both products of the block BEFORE their normalisations - y = linear1(cat[s, v2s(v)]) before bn1 + LeakyReLU,
+        v_lin = linear2(v) before VectorBN and the gate - for a consumer that runs bn1, bn2 and what follows them in its own passes
+        (the classifier's tail, _ops.GlobalMaxMeanPoolBNV).  Rows path only; v_lin may still be in flight on the side stream."""
+        return self._forward_rows(x, prebn=True, pretail=True)
+
+    def _forward_rows(self, x, prebn=False, pretail=False):
         s, v = x
         rows = s.numel() // max(s.shape[-1], 1)
         if config.TWO_STREAM_BLOCKS and rows >= config.TWO_STREAM_MIN_ROWS and s.is_cuda:
@@ -372,6 +378,8 @@ class SVBlock(nn.Module):
                 s_cat, v_scale = fused
             else:
                 v_scale = self._gate(s)
+            if pretail:                                  # (the consumer forks / joins the side stream itself)
+                return (self.linear1(s_cat if fused is not None else self._cat_s_v2s(s, v)), v_lin, v_scale)
             side.wait_stream(main)                       # (the gate came from the main stream)
             with torch.cuda.stream(side):
                 v_out = self.bn2(v_lin, gate=v_scale)
@@ -388,6 +396,8 @@ class SVBlock(nn.Module):
             s = batch_norm_act(self.bn1, s, _ACT_LEAKY, self.relu.negative_slope)
 
         v = self.linear2(v, vstats=True)
+        if pretail:
+            return (s, v, v_scale)
         v = self.bn2(v, gate=v_scale)
         return (s, v)
 

@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.decisions import tapped
+
 from oracle import sv_ref
 from tests.common import compare_case
 from tests.golden import cases as C
@@ -309,6 +311,68 @@ def test_bn_pool_fused_equals_bn_act_then_pool(training, hip_device):
     for n in ("dy", "db", "dgamma", "dbeta"):
         a_, b_ = res[True][n], res[False][n]
         assert float((a_ - b_).abs().max()) <= 1e-5 * max(float(b_.abs().max()), 1e-6), n
+
+
+@pytest.mark.parametrize("training", [True, False], ids=["train", "eval"])
+@pytest.mark.parametrize("cfg", [(3, 300, 70, 45, True), (2, 1024, 64, 170, True), (4, 257, 96, 100, False), (2, 256, 32, 64, True)],
+                         ids=["c45", "c170", "c100_fp", "c64"])
+def test_vector_tail_fused_equals_vectorbn_v2s_then_pool(cfg, training, hip_device):
+    """_ops.GlobalMaxMeanPoolBNV (csrc/vtail.hip: conv5's VectorBN + gate, svfuse's Vector2Scalar and the [max | mean] pooling of its
+    half in one pass over linear2's product each way; sv_layers.py:86-102,111-129,193-194,206-220, sv_dgcnn_cls.py:68-74) against the
+    layer-wise chain VBN -> V2S -> GlobalMaxMeanPoolBN on the same inputs: pooled maxima bit-identical (same expressions, same
+    order), means / statistics / every gradient to 2e-5 of the tensor's largest element (other summation orders), arg-max identical."""
+    from svnet_amd import _ops
+    B, N, Ca, C, binary = cfg
+    g = torch.Generator().manual_seed(33 + C)
+    y = torch.randn(B, N, Ca, generator=g) * 2.0
+    v = torch.randn(B, N, 3, C, generator=g)
+    v[0, 5] = v[0, 77]                                       # ties: the first index takes the max gradient
+    v[1, 3, :, ::7] = 0.0                                    # zero vectors: norm backward at 0 is 0 (SURVEY App. C6)
+    gate = torch.rand(B, C, generator=g) * 0.8 + 0.1
+    Wz = torch.randn(3, C, generator=g)
+    scz = (torch.rand(1, 3, generator=g) + 0.5) if binary else None
+    w = torch.randn(B, 2 * (Ca + 3 * C), generator=g).to(hip_device)
+    res = {}
+    for fused in (True, False):
+        bn1 = torch.nn.BatchNorm1d(Ca).to(hip_device).train(training)
+        bn2 = torch.nn.BatchNorm1d(C).to(hip_device).train(training)
+        with torch.no_grad():
+            bn1.weight.copy_(torch.linspace(-1.0, 1.5, Ca)); bn1.bias.copy_(torch.linspace(0.3, -0.3, Ca))
+            bn2.weight.copy_(torch.linspace(1.5, -0.5, C)); bn2.bias.copy_(torch.linspace(-0.2, 0.4, C))       # both signs of gamma
+            for bn in (bn1, bn2):
+                bn.running_mean.copy_(torch.linspace(0.8, 1.6, bn.num_features)); bn.running_var.copy_(torch.linspace(0.5, 2.0, bn.num_features))
+        yd, vd, gd = (t.to(hip_device).requires_grad_(True) for t in (y, v, gate))
+        Wd = Wz.to(hip_device).requires_grad_(True)
+        sd = None if scz is None else scz.to(hip_device).requires_grad_(True)
+        n1, n2 = (bn1.num_batches_tracked, bn2.num_batches_tracked) if training else (None, None)
+        with tapped() as tap:
+            if fused:
+                out = _ops.GlobalMaxMeanPoolBNV.apply(yd, vd, gd, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn2.weight, bn2.bias,
+                                                      bn2.running_mean, bn2.running_var, Wd, sd, training, 1, 0.2, n1, n2, bn1.eps, bn1.momentum)
+            else:
+                v5 = _ops.VBN.apply(vd, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, gd, N, training, n2, bn2.eps, bn2.momentum)
+                sv, _ = _ops.V2S.apply(v5, Wd, sd, training)
+                out = _ops.GlobalMaxMeanPoolBN.apply(yd, sv, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, training, 1, 0.2, n1,
+                                                     bn1.eps, bn1.momentum)
+        (out * w).sum().backward()
+        torch.cuda.synchronize()
+        res[fused] = dict(out=out.detach().cpu(), dy=yd.grad.cpu(), dv=vd.grad.cpu(), dgate=gd.grad.cpu(), dWz=Wd.grad.cpu(),
+                          dscz=None if sd is None else sd.grad.cpu(), dg1=bn1.weight.grad.cpu(), db1=bn1.bias.grad.cpu(),
+                          dg2=bn2.weight.grad.cpu(), db2=bn2.bias.grad.cpu(), rm2=bn2.running_mean.cpu().clone(), rv2=bn2.running_var.cpu().clone(),
+                          nbt2=int(bn2.num_batches_tracked), arg=tap["pools"][-1].cpu())
+    Ct = Ca + 3 * C
+    assert torch.equal(res[True]["out"][:, :Ca], res[False]["out"][:, :Ca])                  # max a: the same kernel
+    if C > 96:       # (the layer-wise Vector2Scalar sums its frame over 64 lanes from 97 channels on, like the fused pass: the same expressions)
+        assert torch.equal(res[True]["out"][:, :Ct], res[False]["out"][:, :Ct])              # [max a | max b]
+        assert torch.equal(res[True]["arg"], res[False]["arg"])
+    assert res[True]["nbt2"] == res[False]["nbt2"] == (1 if training else 0)
+    for n in ("out", "dy", "dv", "dgate", "dWz", "dscz", "dg1", "db1", "dg2", "db2", "rm2", "rv2"):
+        a_, b_ = res[True][n], res[False][n]
+        if b_ is None:
+            assert a_ is None
+            continue
+        assert torch.isfinite(a_).all(), n
+        assert float((a_ - b_).abs().max()) <= 2e-5 * max(float(b_.abs().max()), 1e-6), (n, float((a_ - b_).abs().max()), float(b_.abs().max()))
 
 
 # ----------------------------------------------------------------------------- CatSink with a level that is not fused (ADVICE r3, medium)

@@ -21,6 +21,7 @@ def main():
     args = ap.parse_args()
     wl = bench.WORKLOADS["dgcnn_cls"]
     print("# oracle (torch CPU ops) of %s, N=%d k=%d; median of %d after 1 warm-up" % (wl["name"], wl["N"], wl["k"], args.timed))
+    print("# threads = bench.cpu_share() = %d" % bench.cpu_share())
     print("# B  fwd+loss+bwd clouds/s  forward-only clouds/s  wall s of the leg  threads  cpu")
     for b in [int(t) for t in args.batches.split(",")]:
         t0 = time.time()

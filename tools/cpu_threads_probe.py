@@ -19,7 +19,6 @@ for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys
 print("loadavg", open("/proc/loadavg").read().strip())
 wl = bench.WORKLOADS["dgcnn_cls"]
 for n in [int(a) for a in (sys.argv[1] if len(sys.argv) > 1 else "128,64,32,16,8").split(",")]:
-    torch.set_num_threads(n)
     t0 = time.time()
-    r = bench.cpu_baseline(wl, sample_b=8, timed=1)
+    r = bench.cpu_baseline(wl, sample_b=8, timed=1, threads=n)
     print("threads %3d: fwd+loss+bwd %.4f clouds/s, forward only %.4f clouds/s (leg %.1f s)" % (n, r["value"], r["forward_only_value"], time.time() - t0), flush=True)
