@@ -24,6 +24,35 @@ __device__ __forceinline__ unsigned long long vt_pack_key(float v, uint32_t r) {
     return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - r);
 }
 
+// ---- nine wave-wide sums per point (the 3 x 3 frame): eight of them packed (18 VALU: permlane swaps fold two quantities per step, as
+// edgeblock_bwd.hip wave_sum8_packed) + one plain, results as WAVE-UNIFORM scalars (v_readlane) - nine separate 6-step DPP chains were
+// most of the kernel's dependent latency
+template <int CTRL>
+__device__ __forceinline__ float vt_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float vt_fold32(float a, float b) {      // lanes 0-31: sum of a's halves, lanes 32-63: of b's
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float vt_fold16(float a, float b) {      // rows: a.r0+a.r1 | b.r0+b.r1 | a.r2+a.r3 | b.r2+b.r3
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float vt_lane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ void vt_sum9(const float (&p)[3][J], int lane, float (&z)[3][J]) {
+    const float x0 = vt_fold16(vt_fold32(p[0][0], p[0][1]), vt_fold32(p[0][2], p[1][0]));   // rows: s0 | s2 | s1 | s3
+    const float x1 = vt_fold16(vt_fold32(p[1][1], p[1][2]), vt_fold32(p[2][0], p[2][1]));   // rows: s4 | s6 | s5 | s7
+    const bool hi = (lane & 8) != 0;
+    float y = (hi ? x1 : x0) + vt_dpp<0x128>(hi ? x0 : x1);                                  // row_ror:8 - 8-lane groups: s0 s4 s2 s6 s1 s5 s3 s7
+    y += vt_dpp<0xB1>(y);
+    y += vt_dpp<0x4E>(y);
+    y += vt_dpp<0x141>(y);
+    z[0][0] = vt_lane(y, 0);  z[1][1] = vt_lane(y, 8);  z[0][2] = vt_lane(y, 16); z[2][0] = vt_lane(y, 24);
+    z[0][1] = vt_lane(y, 32); z[1][2] = vt_lane(y, 40); z[1][0] = vt_lane(y, 48); z[2][1] = vt_lane(y, 56);
+    z[2][2] = vt_lane(group_sum_dpp<64>(p[2][2]), 0);
+}
+
 struct VtStats {        // training: the sliced fp64 sums of svnet_colstats_f64(kind 1); every lane derives its channels' statistics itself
     const double* sums; float* mean_out; float* invstd_out; float* rmean; float* rvar; long long* nbt;
     const float* mean_in; const float* invstd_in;      // eval (sums == nullptr): the running statistics' mean / invstd
@@ -36,38 +65,58 @@ struct VtChan {          // per-lane constants of its CPL channels
     bool ok[CPL];
 };
 
+// (training: wave 0 of the workgroup derives the statistics from the 2 x 16 fp64 slices of its channels - 96 loads, an fp64 division and
+//  square root per lane - and hands them to the other waves through `lstat` [2][64 * CPL] floats of LDS; ends on a barrier)
 template <int CPL>
 __device__ __forceinline__ void vt_load_chan(VtChan<CPL>& ch, const VtStats& st, const float* gamma, const float* beta, const float* gate,
-                                             const float* w, int64_t cloud, int64_t M, int C, int lane, bool keeper) {
+                                             const float* w, int64_t cloud, int64_t M, int C, int lane, int wave, bool keeper, float* lstat) {
+    if (st.sums) {
+        if (wave == 0) {
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) {
+                const int c = lane + 64 * t;
+                const int cc = c < C ? c : 0;
+                // bn_finalize_kernel's arithmetic (norm.hip)
+                const double m = svnet_slices_total(st.sums, 2 * C, cc) / (double)M;
+                double var = svnet_slices_total(st.sums, 2 * C, C + cc) / (double)M - m * m;
+                if (var < 0.0) var = 0.0;
+                const float mu = (float)m, is = (float)(1.0 / sqrt(var + (double)st.eps));
+                lstat[c] = mu;
+                lstat[64 * CPL + c] = is;
+                if (keeper && c < C) {
+                    st.mean_out[c] = mu;
+                    st.invstd_out[c] = is;
+                    if (st.rmean) st.rmean[c] = (1.f - st.momentum) * st.rmean[c] + st.momentum * (float)m;
+                    if (st.rvar) {
+                        const double unb = (M > 1) ? var * ((double)M / (double)(M - 1)) : var;
+                        st.rvar[c] = (1.f - st.momentum) * st.rvar[c] + st.momentum * (float)unb;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int t = 0; t < CPL; ++t) {
         const int c = lane + 64 * t;
         ch.ok[t] = c < C;
         const int cc = ch.ok[t] ? c : 0;
-        if (st.sums) {       // bn_finalize_kernel's arithmetic (norm.hip)
-            const double m = svnet_slices_total(st.sums, 2 * C, cc) / (double)M;
-            double var = svnet_slices_total(st.sums, 2 * C, C + cc) / (double)M - m * m;
-            if (var < 0.0) var = 0.0;
-            ch.mu[t] = (float)m;
-            ch.is[t] = (float)(1.0 / sqrt(var + (double)st.eps));
-            if (keeper && ch.ok[t]) {
-                st.mean_out[c] = ch.mu[t];
-                st.invstd_out[c] = ch.is[t];
-                if (st.rmean) st.rmean[c] = (1.f - st.momentum) * st.rmean[c] + st.momentum * (float)m;
-                if (st.rvar) {
-                    const double unb = (M > 1) ? var * ((double)M / (double)(M - 1)) : var;
-                    st.rvar[c] = (1.f - st.momentum) * st.rvar[c] + st.momentum * (float)unb;
-                }
-            }
+        if (st.sums) {
+            ch.mu[t] = lstat[c];
+            ch.is[t] = lstat[64 * CPL + c];
         } else {
             ch.mu[t] = st.mean_in[cc];
             ch.is[t] = st.invstd_in[cc];
         }
         ch.ga[t] = gamma[cc];
         ch.be[t] = beta[cc];
-        ch.gt[t] = gate ? gate[cloud * C + cc] : 1.f;
+        ch.gt[t] = ch.ok[t] ? (gate ? gate[cloud * C + cc] : 1.f) : 0.f;     // (a dead channel's gate and weights are 0: all it adds is 0)
 #pragma unroll
         for (int j = 0; j < J; ++j) ch.w[j][t] = ch.ok[t] ? w[j * C + c] : 0.f;
+        // (pinned in registers: left alone, the compiler re-loads these per-channel constants from memory inside the point loop - 24
+        //  loads per two points whose waits sit in the middle of the dependent chain - to save the registers)
+        asm volatile("" : "+v"(ch.mu[t]), "+v"(ch.is[t]), "+v"(ch.ga[t]), "+v"(ch.be[t]), "+v"(ch.gt[t]));
+        asm volatile("" : "+v"(ch.w[0][t]), "+v"(ch.w[1][t]), "+v"(ch.w[2][t]));
     }
 }
 
@@ -84,25 +133,28 @@ __device__ __forceinline__ void vt_load_row(float (&a)[3][CPL], const float* __r
 }
 
 // VectorBN + gate of one point's channels (vbn_fwd_kernel's expressions) and the frame z of Vector2Scalar (v2s_fwd_kernel's)
+// (one division per channel: v * (BN(n) / n * gate) - vbn_fwd_kernel divides every component, v / n * BN(n) * gate: the same value to an ulp)
 template <int CPL>
 __device__ __forceinline__ void vt_point(const float (&a)[3][CPL], const VtChan<CPL>& ch, float (&x)[3][CPL], float (&n)[CPL], float (&rr)[CPL],
-                                         float (&z)[3][J]) {
+                                         float (&z)[3][J], int lane) {
 #pragma unroll
     for (int t = 0; t < CPL; ++t) {
         n[t] = sqrtf(a[0][t] * a[0][t] + a[1][t] * a[1][t] + a[2][t] * a[2][t]) + VT_VEPS;
         rr[t] = (n[t] - ch.mu[t]) * ch.is[t] * ch.ga[t] + ch.be[t];
+        const float q = rr[t] / n[t] * ch.gt[t];        // (no branch around the division: a dead channel reads channel 0, n > 0, gate 0)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) x[i][t] = ch.ok[t] ? a[i][t] / n[t] * rr[t] * ch.gt[t] : 0.f;
+        for (int i = 0; i < 3; ++i) x[i][t] = a[i][t] * q;
     }
+    float p[3][J];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-            float p = 0.f;
+            p[i][j] = 0.f;
 #pragma unroll
-            for (int t = 0; t < CPL; ++t) p = fmaf(x[i][t], ch.w[j][t], p);
-            z[i][j] = group_sum_dpp<64>(p);
+            for (int t = 0; t < CPL; ++t) p[i][j] = fmaf(x[i][t], ch.w[j][t], p[i][j]);
         }
+    vt_sum9(p, lane, z);
 }
 
 // ---- forward: grid (row chunks, clouds), 4 waves; wave w takes points r0 + w, r0 + w + 4, ... of the chunk
@@ -114,42 +166,50 @@ __global__ __launch_bounds__(256) void vtail_fwd_kernel(const float* __restrict_
     constexpr int NO = J * CPL;                          // outputs per lane
     __shared__ unsigned long long lkey[4][NO * 64];
     __shared__ float lsum[4][NO * 64];
+    __shared__ float lstat[2 * 64 * CPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t cloud = blockIdx.y;
     const int r0 = blockIdx.x * rows_per_chunk, r1 = min(N, r0 + rows_per_chunk);
     const int64_t M = (int64_t)gridDim.y * N;
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && st.sums && st.nbt) *st.nbt += 1;
     VtChan<CPL> ch;
-    vt_load_chan<CPL>(ch, st, gamma, beta, gate, w, cloud, M, C, lane, blockIdx.x == 0 && blockIdx.y == 0 && wave == 0);
+    vt_load_chan<CPL>(ch, st, gamma, beta, gate, w, cloud, M, C, lane, wave, blockIdx.x == 0 && blockIdx.y == 0, lstat);
 
     float best[CPL][J], sum[CPL][J];
     uint32_t bi[CPL][J];
+    const bool any = r0 + wave < r1;
 #pragma unroll
     for (int t = 0; t < CPL; ++t)
 #pragma unroll
-        for (int j = 0; j < J; ++j) { best[t][j] = -INFINITY; sum[t][j] = 0.f; bi[t][j] = 0xFFFFFFFFu; }
+        for (int j = 0; j < J; ++j) { best[t][j] = -INFINITY; sum[t][j] = 0.f; bi[t][j] = (uint32_t)(r0 + wave); }
 
-    float a[3][CPL], an[3][CPL];
-    int r = r0 + wave;
-    if (r < r1) vt_load_row<CPL>(a, v, cloud * N + r, C, lane);
-    for (; r < r1; r += 4) {
-        const int rn = min(r + 4, N - 1);                  // next point of this wave, requested before the current one is consumed (clamped)
-        vt_load_row<CPL>(an, v, cloud * N + rn, C, lane);
-        __builtin_amdgcn_sched_barrier(0);
+    // one point: VectorBN + gate, frame, the 3 CPL scalars of this lane, running [max | sum].  `live` false (a clamped request past the
+    // chunk's end) leaves the accumulators alone.  The body has no branch: basic-block boundaries made the waitcnt pass drain the requests.
+    auto point = [&](const float (&a)[3][CPL], int r, bool live) {
         float x[3][CPL], n[CPL], rr[CPL], z[3][J];
-        vt_point<CPL>(a, ch, x, n, rr, z);
+        vt_point<CPL>(a, ch, x, n, rr, z, lane);
 #pragma unroll
         for (int t = 0; t < CPL; ++t)
 #pragma unroll
             for (int j = 0; j < J; ++j) {
-                const float s = x[0][t] * z[0][j] + x[1][t] * z[1][j] + x[2][t] * z[2][j];
-                sum[t][j] += s;
-                if (s > best[t][j] || bi[t][j] == 0xFFFFFFFFu) { best[t][j] = s; bi[t][j] = (uint32_t)r; }   // strict '>': first index
+                const float sv = x[0][t] * z[0][j] + x[1][t] * z[1][j] + x[2][t] * z[2][j];
+                sum[t][j] += live ? sv : 0.f;
+                const bool up = live && sv > best[t][j];                  // strict '>': the first index keeps a tie
+                best[t][j] = up ? sv : best[t][j];
+                bi[t][j] = up ? (uint32_t)r : bi[t][j];
             }
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int t = 0; t < CPL; ++t) a[i][t] = an[i][t];
+    };
+    // two register sets, requested alternately one point ahead (a rotated set - cur = next - made the copy wait for the request)
+    float a[3][CPL], b[3][CPL];
+    const int64_t base = cloud * N;
+    vt_load_row<CPL>(a, v, base + min(r0 + wave, N - 1), C, lane);
+    for (int r = r0 + wave; r < r1; r += 8) {
+        vt_load_row<CPL>(b, v, base + min(r + 4, N - 1), C, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        point(a, r, true);
+        vt_load_row<CPL>(a, v, base + min(r + 8, N - 1), C, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        point(b, r + 4, r + 4 < r1);
     }
     // the four waves' results of a column: larger key (value, then lower row) and the sums in wave order (bit-reproducible)
 #pragma unroll
@@ -157,7 +217,7 @@ __global__ __launch_bounds__(256) void vtail_fwd_kernel(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             const int slot = (t * J + j) * 64 + lane;
-            lkey[wave][slot] = bi[t][j] == 0xFFFFFFFFu ? 0ull : vt_pack_key(best[t][j], bi[t][j]);
+            lkey[wave][slot] = any ? vt_pack_key(best[t][j], bi[t][j]) : 0ull;
             lsum[wave][slot] = sum[t][j];
         }
     __syncthreads();
@@ -189,9 +249,20 @@ __global__ __launch_bounds__(256) void vtail_finish_kernel(const unsigned long l
         const unsigned long long kk = keys[e];
         uint32_t u = (uint32_t)(kk >> 32);
         u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+        // (the chunks' partial sums in order - bit-reproducible - with eight loads in flight: one dependent L2 round trip per chunk made
+        //  this 16 K-element kernel 8 - 10 us long; 32-bit division: total < 2^20)
         float s = 0.f;
-        for (int64_t c = 0; c < chunks; ++c) s += part[c * total + e];
-        const int64_t o = e / inner, i = e - o * inner;
+        int64_t c = 0;
+        for (; c + 7 < chunks; c += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = part[(c + u) * total + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += t[u];
+        }
+        for (; c < chunks; ++c) s += part[c * total + e];
+        const uint32_t o32 = (uint32_t)e / (uint32_t)inner;
+        const int64_t o = o32, i = e - o * inner;
         out_max[o * out_ld + i] = __uint_as_float(u);
         out_mean[o * out_ld + i] = s * invR;
         argmax[e] = (int32_t)(0xFFFFFFFFu - (uint32_t)(kk & 0xFFFFFFFFull));
@@ -216,7 +287,7 @@ __global__ __launch_bounds__(256) void vtail_bwd_kernel(const float* __restrict_
     VtStats st{};
     st.mean_in = mean; st.invstd_in = invstd;
     VtChan<CPL> ch;
-    vt_load_chan<CPL>(ch, st, gamma, beta, gate, w, cloud, 0, C, lane, false);
+    vt_load_chan<CPL>(ch, st, gamma, beta, gate, w, cloud, 0, C, lane, wave, false, nullptr);
     const float invR = 1.f / (float)N;
     float gx[CPL][J], gm[CPL][J];
     int am[CPL][J];
@@ -238,60 +309,67 @@ __global__ __launch_bounds__(256) void vtail_bwd_kernel(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < J; ++j) gxw[j][t] = 0.f;
     }
-    float a[3][CPL], an[3][CPL];
-    int r = r0 + wave;
-    if (r < r1) vt_load_row<CPL>(a, v, cloud * N + r, C, lane);
-    for (; r < r1; r += 4) {
-        const int rn = min(r + 4, N - 1);
-        vt_load_row<CPL>(an, v, cloud * N + rn, C, lane);
-        __builtin_amdgcn_sched_barrier(0);
+    // one point (see the forward kernel: no branch in the body; `live` false = a clamped request past the chunk's end, whose pooled
+    // gradient is taken as 0 - every sum it feeds then receives 0 - and whose row is not stored)
+    auto point = [&](const float (&a)[3][CPL], int r, bool live) {
         float x[3][CPL], n[CPL], rr[CPL], z[3][J];
-        vt_point<CPL>(a, ch, x, n, rr, z);
+        vt_point<CPL>(a, ch, x, n, rr, z, lane);
         // pooled gradient of this point's s_v, Vector2Scalar's backward (v2s_bwd_kernel's expressions)
         float d[CPL][J], dz[3][J];
 #pragma unroll
         for (int t = 0; t < CPL; ++t)
 #pragma unroll
-            for (int j = 0; j < J; ++j) d[t][j] = gm[t][j] + (am[t][j] == r ? gx[t][j] : 0.f);
+            for (int j = 0; j < J; ++j) d[t][j] = live ? gm[t][j] + (am[t][j] == r ? gx[t][j] : 0.f) : 0.f;
+        {
+            float pd[3][J];
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+            for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < J; ++j) {
-                float pd = 0.f;
+                for (int j = 0; j < J; ++j) {
+                    pd[i][j] = 0.f;
 #pragma unroll
-                for (int t = 0; t < CPL; ++t) pd = fmaf(d[t][j], x[i][t], pd);
-                dz[i][j] = group_sum_dpp<64>(pd);
-            }
+                    for (int t = 0; t < CPL; ++t) pd[i][j] = fmaf(d[t][j], x[i][t], pd[i][j]);
+                }
+            vt_sum9(pd, lane, dz);
+        }
         const int64_t m = cloud * N + r;
 #pragma unroll
         for (int t = 0; t < CPL; ++t) {
             float g[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                float s = 0.f;
+                float sg = 0.f;
 #pragma unroll
-                for (int j = 0; j < J; ++j) s += d[t][j] * z[i][j] + dz[i][j] * ch.w[j][t];
-                g[i] = s;
+                for (int j = 0; j < J; ++j) sg += d[t][j] * z[i][j] + dz[i][j] * ch.w[j][t];
+                g[i] = sg;
             }
 #pragma unroll
             for (int j = 0; j < J; ++j) gxw[j][t] += dz[0][j] * x[0][t] + dz[1][j] * x[1][t] + dz[2][j] * x[2][t];
-            if (ch.ok[t]) {
+            if (ch.ok[t] && live) {                      // (exec-masked stores, no branch)
                 const int c = lane + 64 * t;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) g5[(m * 3 + i) * C + c] = g[i];
-                // VectorBN's reduce pass on g = dL/dv5 (vbn_bwd_reduce_kernel's expressions)
-                const float nh = (n[t] - ch.mu[t]) * ch.is[t];
-                const float gv = g[0] * a[0][t] + g[1] * a[1][t] + g[2] * a[2][t];
-                gsum[t] += gv * (rr[t] / n[t]);
-                const float dr = gv * ch.gt[t] / n[t];
-                acc0[t] += (double)dr;
-                acc1[t] += (double)dr * (double)nh;
             }
+            // VectorBN's reduce pass on g = dL/dv5 (vbn_bwd_reduce_kernel's expressions); a dead channel's g is 0
+            const float nh = (n[t] - ch.mu[t]) * ch.is[t];
+            const float gv = g[0] * a[0][t] + g[1] * a[1][t] + g[2] * a[2][t];
+            const float rn = 1.f / n[t];
+            gsum[t] += gv * (rr[t] * rn);
+            const float dr = gv * ch.gt[t] * rn;
+            acc0[t] += (double)dr;
+            acc1[t] += (double)dr * (double)nh;
         }
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int t = 0; t < CPL; ++t) a[i][t] = an[i][t];
+    };
+    float a[3][CPL], b[3][CPL];
+    const int64_t base = cloud * N;
+    vt_load_row<CPL>(a, v, base + min(r0 + wave, N - 1), C, lane);
+    for (int r = r0 + wave; r < r1; r += 8) {
+        vt_load_row<CPL>(b, v, base + min(r + 4, N - 1), C, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        point(a, r, true);
+        vt_load_row<CPL>(a, v, base + min(r + 8, N - 1), C, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        point(b, r + 4, r + 4 < r1);
     }
     // workgroup sums in wave order, then ONE add per output and workgroup
 #pragma unroll
@@ -327,10 +405,10 @@ __global__ __launch_bounds__(256) void vtail_bwd_kernel(const float* __restrict_
 }
 
 inline void vtail_chunks(int64_t B, int64_t N, int64_t& chunks, int64_t& rpc) {
-    chunks = svnet_cdiv(256 * 8, B);                      // ~8 workgroups per CU
-    if (chunks > svnet_cdiv(N, 16)) chunks = svnet_cdiv(N, 16);
+    chunks = svnet_cdiv(256 * 3, B);                      // ~3 workgroups per CU: a workgroup's set-up (the channels' statistics and
+    if (chunks > svnet_cdiv(N, 32)) chunks = svnet_cdiv(N, 32);   // constants, its final LDS combine + atomics) is paid per workgroup
     if (chunks < 1) chunks = 1;
-    rpc = svnet_cdiv(svnet_cdiv(N, chunks), 4) * 4;
+    rpc = svnet_cdiv(svnet_cdiv(N, chunks), 8) * 8;       // (two points per wave and loop trip)
     chunks = svnet_cdiv(N, rpc);
 }
 

@@ -32,9 +32,16 @@ for it in range(3):
     torch.cuda.synchronize()
     # (the classifier's own tail, sv_dgcnn_cls.py:69-74: bn1 + LeakyReLU of conv5 inside the pooling pass)
     bn = blk.bn1
-    y5, v5 = blk.forward_prebn((s, v))
-    sv5 = fuse.v2s(v5)
-    pooled = _ops.GlobalMaxMeanPoolBN.apply(y5, sv5, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, 1, 0.2, bn.num_batches_tracked, bn.eps, 0.1)
+    if os.environ.get("SVNET_NO_VTAIL"):
+        y5, v5 = blk.forward_prebn((s, v))
+        sv5 = fuse.v2s(v5)
+        pooled = _ops.GlobalMaxMeanPoolBN.apply(y5, sv5, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, 1, 0.2, bn.num_batches_tracked, bn.eps, 0.1)
+    else:           # the vector half's tail as one pass each way (csrc/vtail.hip)
+        bn2, fz = blk.bn2.bn, fuse.v2s.linear
+        y5, v_lin, gate = blk.forward_pretail((s, v))
+        pooled = _ops.GlobalMaxMeanPoolBNV.apply(y5, v_lin, gate, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn2.weight, bn2.bias,
+                                                 bn2.running_mean, bn2.running_var, fz.weight, fz.scale, True, 1, 0.2, bn.num_batches_tracked,
+                                                 bn2.num_batches_tracked, bn.eps, 0.1)
     mark = len(records)
     pooled.sum().backward()
     torch.cuda.synchronize()
