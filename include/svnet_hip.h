@@ -47,7 +47,7 @@ int svnet_slices_sum_f64(double* buf, int64_t L, void* stream);
  * changes its required length (200: sliced accumulators, SVNET_SLICED_LEN; 400: this header; 401: the totals of a sliced accumulator are
  * written by its consumer, svnet_slices_sum_*; 402: GX of svnet_v2s_bwd_*, gw of svnet_xyzblock_bwd_f32 and col_sum of svnet_gemm_f32 are sliced accumulators; 403: svnet_binweight_grad_f32 takes sliced inputs).  svnet_version() returns the value the
  * library was BUILT with: a caller compiled against another header must refuse to run (svnet_amd/_lib.py does).                   */
-#define SVNET_ABI_VERSION 408
+#define SVNET_ABI_VERSION 409
 int svnet_version(void);
 const char* svnet_last_error(void);
 
@@ -160,6 +160,14 @@ int svnet_binweight_pack_i8(const float* W, int64_t O, int64_t K, int8_t* w_i8, 
 int svnet_binlinear_i8_fwd_f32(const float* x, int64_t ldx, const float* beta, const int8_t* w_i8, const float* scale,
                                const float* bias, int64_t M, int64_t K, int64_t O, float* y, uint64_t* x_sign, uint64_t* x_nz,
                                uint64_t* x_ste, double* col_sums, void* stream);
+/* The same layer when part of its input is CONSTANT over the rows of a cloud (the broadcast half of a concatenation:
+ * sv_dgcnn_partseg.py:115-118 `repeat` + `cat`, sv_pointnet_cls.py:43-52 `expand_as` + `svcat`): x [M, K] holds only the per-point
+ * columns, cloud_n [M / rows_per_cloud, O] the integer counts (as floats) of the per-cloud columns - svnet_binlinear_fwd_f32 over the
+ * B per-cloud rows with scale = 1 -, and y[m,o] = scale[o] * (count(x[m]) + cloud_n[m / rows_per_cloud, o]) (+ bias).  The sum of the two
+ * counts is the count over the full row: outputs and col_sums identical to the product over the materialised concatenation.      */
+int svnet_binlinear_i8_cloud_fwd_f32(const float* x, int64_t ldx, const float* beta, const int8_t* w_i8, const float* scale,
+                                     const float* bias, int64_t M, int64_t K, int64_t O, float* y, uint64_t* x_sign, uint64_t* x_nz,
+                                     uint64_t* x_ste, double* col_sums, const float* cloud_n, int64_t rows_per_cloud, void* stream);
 /* Chain rule from GX[o,k] = sum_m g[m,o] x_eff[m,k] to the parameters of a bw layer (App. C2):
  *   dW[o,k] = scale[o]*GX[o,k]*[|W[o,k]|<=1.2],  dscale[o] = sum_k w_b[o,k]*GX[o,k];  accumulate != 0 adds to dW/dscale. */
 /* gx_sliced != 0: GX is a sliced accumulator of O*K floats (SVNET_SLICED_LEN) whose slices are added up on the way in.

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVNET_DIAG_LIB") or os.path.join(_HERE, "libsvnet_hip.so")    # (SVNET_DIAG_LIB: an ablation build, tools/ only)
 _lib = None
-ABI_VERSION = 408       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
+ABI_VERSION = 409       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
 
 c_p = ctypes.c_void_p
 c_i64 = ctypes.c_int64
@@ -172,6 +172,7 @@ SIGNATURES = {
     "svnet_binweight_i8_bytes": (c_sz, [c_i64, c_i64]),
     "svnet_binweight_pack_i8": (c_int, [c_p, c_i64, c_i64, c_p, c_p]),
     "svnet_binlinear_i8_fwd_f32": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "svnet_binlinear_i8_cloud_fwd_f32": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
     "svnet_v2s_fwd_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "svnet_v2s_bwd_f32": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "svnet_v2s_cat_fwd_f32": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_i64, c_p]),

@@ -642,6 +642,135 @@ class BinLinear(torch.autograd.Function):
         return dx, dW, dbeta, dsc, dbias, None
 
 
+def _binweight_cols(W, scale, k0, k1, i8=False):
+    """_binweight() of the column block W[:, k0:k1] of a bw layer's weight [O,K] (a contiguous copy is packed; cached per
+    (parameter, block) like the whole-matrix forms and re-packed with them when the parameter changes)."""
+    import weakref
+    O, dev = W.shape[0], W.device
+    Kb = k1 - k0
+    w_ref, s_ref = weakref.ref(W), (None if scale is None else weakref.ref(scale))
+
+    def build():
+        out = {"w_sign": torch.empty((O, _words(Kb)), dtype=torch.int64, device=dev), "w_nz": torch.empty((O, _words(Kb)), dtype=torch.int64, device=dev),
+               "w_b": torch.empty((O, Kb), dtype=torch.float32, device=dev),
+               "w_i8": torch.empty((_lib.lib().svnet_binweight_i8_bytes(O, Kb),), dtype=torch.int8, device=dev) if i8 else None}
+
+        def rebuild():
+            Wp = w_ref()
+            if Wp is None or (s_ref is not None and s_ref() is None):
+                return
+            Wc = Wp.detach().reshape(O, -1)[:, k0:k1].contiguous()
+            call("svnet_binweight_prepare_f32", _p(Wc), None, O, Kb, _p(out["w_sign"]), _p(out["w_nz"]), _p(out["w_b"]), None, _stream())
+            if out["w_i8"] is not None:
+                call("svnet_binweight_pack_i8", _p(Wc), O, Kb, _p(out["w_i8"]), _stream())
+        rebuild()
+        return out, rebuild
+    return PLANES.get("bwcols:%d:%d:%d" % (k0, k1, int(i8)), (W,) if scale is None else (W, scale), build)
+
+
+def _cloud_planes_as_rows(planes, B, N, K):
+    """Row-sliced planes [ceil(B/64), K] of B per-cloud rows -> the planes [ceil(B*N/64), K] of the B*N rows in which every cloud's row
+    is repeated N times (test instrumentation only: what the binarized broadcast half of a concatenation looks like to the decision tap)."""
+    dev = planes[0].device
+    out = []
+    shifts = torch.arange(64, device=dev, dtype=torch.int64)
+    for pl in planes:
+        bits = ((pl.view(-1, 1, K) >> shifts.view(1, 64, 1)) & 1).reshape(-1, K)[:B]                # [B,K]
+        rows = bits.repeat_interleave(N, dim=0)                                                     # [B*N,K]
+        pad = (-rows.shape[0]) % 64
+        if pad:
+            rows = torch.cat([rows, torch.zeros((pad, K), dtype=torch.int64, device=dev)], dim=0)
+        out.append((rows.view(-1, 64, K) << shifts.view(1, 64, 1)).sum(dim=1))                      # disjoint bits: sum == or (wraps at bit 63)
+    return out
+
+
+class BinLinearCloud(torch.autograd.Function):
+    """Linear(bw, ba) / Conv1d(binary) (sv_layers.py:35-51, :55-78) on rows whose leading Kc columns are CONSTANT over each cloud's N
+    rows - the layer applied to cat[expand(x_cloud), x_point] (sv_dgcnn_partseg.py:115-121: conv8 on [glob | pooled | label] repeated
+    over the points + the per-point feature) WITHOUT the concatenation:
+
+        y[b,n,o] = scale[o] * (count(x_point[b,n] ; W[:, Kc:]) + count(x_cloud[b] ; W[:, :Kc]))
+
+    The XNOR-popcount sum over a row is the sum over its two column blocks, so the outputs (and the BatchNorm sums the kernel leaves
+    behind) are IDENTICAL to the product over the materialised [B*N, Kc+Kp] rows; the per-cloud block costs B rows instead of B*N
+    (conv8 of sv_dgcnn_partseg: 1 600 of 2 144 columns).  Backward: dL/dy is summed over each cloud's rows once; the per-point block's
+    input / weight gradients are the usual products over Kp columns, the per-cloud block's are products over B rows."""
+
+    @staticmethod
+    def forward(ctx, x_cloud, x_point, W, beta, scale, training=True):
+        global _FUSED_COLSUMS
+        _hip(x_cloud, x_point, W, beta, scale)
+        ctx.training = bool(training)
+        B, N, Kp = x_point.shape
+        Kc = x_cloud.shape[-1]
+        xp = _f32c(x_point).reshape(B * N, Kp)
+        xc = _f32c(x_cloud).reshape(B, Kc)
+        W_in, Wc = W, _f32c(W).reshape(W.shape[0], -1)
+        O, K = Wc.shape
+        if K != Kc + Kp:
+            raise ValueError("BinLinearCloud: weight has %d columns, inputs %d + %d" % (K, Kc, Kp))
+        M = B * N
+        dev = xp.device
+        need_grad = any(ctx.needs_input_grad)
+        sc, bt = _f32c(scale).view(-1), _f32c(beta).view(-1)
+        pk_c = _binweight_cols(W_in, scale, 0, Kc)
+        pk_p = _binweight_cols(W_in, scale, Kc, K, i8=True)
+        keep = need_grad or TAP is not None
+        pl_c = [torch.empty(((B + 63) // 64, Kc), dtype=torch.int64, device=dev) for _ in range(3)] if keep else [None] * 3
+        pl_p = [torch.empty(((M + 63) // 64, Kp), dtype=torch.int64, device=dev) for _ in range(3)] if keep else [None] * 3
+        # the per-cloud block: integer counts of the B rows (scale 1: the values are exact integers in fp32)
+        ones = torch.ones((O,), dtype=torch.float32, device=dev)
+        n_cloud = torch.empty((B, O), dtype=torch.float32, device=dev)
+        call("svnet_binlinear_fwd_f32", _p(xc), Kc, _p(bt), _p(pk_c["w_sign"]), _p(pk_c["w_nz"]), _p(ones), None, B, Kc, O, _p(n_cloud),
+             _p(pl_c[0]), _p(pl_c[1]), _p(pl_c[2]), _stream())
+        y = torch.empty((M, O), dtype=torch.float32, device=dev)
+        sums = _zeros((_sliced_len(2 * O),), torch.float64, dev) if (training and config.FUSE_BN_STATS and K <= 46340) else None
+        call("svnet_binlinear_i8_cloud_fwd_f32", _p(xp), Kp, _p(bt[Kc:]), _p(pk_p["w_i8"]), _p(sc), None, M, Kp, O, _p(y),
+             _p(pl_p[0]), _p(pl_p[1]), _p(pl_p[2]), _p(sums), _p(n_cloud), N, _stream())
+        _FUSED_COLSUMS = (y, y._version, sums) if sums is not None else None
+        if TAP is not None:      # the planes of the full [M, K] rows, as the layer over the materialised concatenation would have recorded them
+            full = [torch.cat([a, b], dim=1).contiguous() for a, b in zip(_cloud_planes_as_rows(pl_c, B, N, Kc), pl_p)]
+            TAP["signs"].append(("rows", M, K, full))
+        if need_grad:
+            ctx.save_for_backward(Wc, sc, pk_c["w_b"], pk_p["w_b"], *pl_c, *pl_p)
+        ctx.meta = (B, N, Kc, Kp, O, x_cloud.shape, x_point.shape, beta.shape, scale.shape, W_in.shape)
+        return y.view(B, N, O)
+
+    @staticmethod
+    def backward(ctx, g):
+        Wc, sc, wb_c, wb_p, cs, cz, cq, ps, pz, pq = ctx.saved_tensors
+        B, N, Kc, Kp, O, cshape, pshape, bshape, sshape, wshape = ctx.meta
+        K, M = Kc + Kp, B * N
+        dev = g.device
+        g2 = _f32c(g).reshape(M, O)
+        # dL/dy summed over each cloud's rows: all the per-cloud block ever sees of it
+        gc = pool_raw(g2, B, N, O, 1)[0]
+        gc = gc * float(N)
+        need_w = ctx.needs_input_grad[2] or ctx.needs_input_grad[4]
+        dxc = dxp = dbeta = dW = dsc = None
+        dbuf_c = _zeros((_sliced_len(Kc),), torch.float32, dev)
+        dbuf_p = _zeros((_sliced_len(Kp),), torch.float32, dev)
+        if ctx.training:
+            dxp = torch.empty((M, Kp), dtype=torch.float32, device=dev)
+            gemm(M, Kp, O, A=g2, a_rs=O, a_cs=1, a_scale=sc, B=wb_p, b_rs=Kp, b_cs=1, b_exact=True, C=dxp, ldc=Kp, mask=pq, col_sum=dbuf_p)
+            dxc = torch.empty((B, Kc), dtype=torch.float32, device=dev)
+            gemm(B, Kc, O, A=gc, a_rs=O, a_cs=1, a_scale=sc, B=wb_c, b_rs=Kc, b_cs=1, b_exact=True, C=dxc, ldc=Kc, mask=cq, col_sum=dbuf_c)
+            call("svnet_slices_sum_f32", _p(dbuf_p), Kp, _stream())
+            call("svnet_slices_sum_f32", _p(dbuf_c), Kc, _stream())
+        else:       # eval: bare sign() has zero gradient (sv_layers.py:38-39)
+            dxp = torch.zeros((M, Kp), dtype=torch.float32, device=dev)
+            dxc = torch.zeros((B, Kc), dtype=torch.float32, device=dev)
+        dbeta = torch.cat([dbuf_c[:Kc], dbuf_p[:Kp]]).view(bshape)
+        if need_w:
+            # GX[o, k] = sum_m g[m,o] x_b[m,k]: the per-cloud columns from the B summed rows, the per-point columns from all rows
+            GX = _zeros((O, K), torch.float32, dev)
+            gemm(Kc, O, B, a_planes=(cs, cz), B=gc, b_rs=O, b_cs=1, C=GX, ldc=1, c_cs=K, accumulate=True)
+            gemm(Kp, O, M, a_planes=(ps, pz), B=g2, b_rs=O, b_cs=1, C=GX[:, Kc:], ldc=1, c_cs=K, accumulate=True)
+            dW, dsc = _binweight_grad(GX, Wc, sc, O, K, ctx.training)
+            dW, dsc = dW.view(wshape), dsc.view(sshape)
+        return dxc.view(cshape), dxp.view(pshape), dW, dbeta, dsc, None
+
+
 class BinLinearBNAct(torch.autograd.Function):
     """act(BatchNorm1d(Linear(bw, ba)(x))) over M <= 64 rows (the classifier heads: sv_dgcnn_cls.py:76-78, sv_pointnet_cls.py:59-60) in
     one packing pass + ONE fused pass forward and two passes backward (csrc/head.hip) instead of ~12 launch-bound kernels per layer.

@@ -42,6 +42,11 @@ BINLINEAR_MFMA = True
 # ... and its kernel leaves the column sums of the output for the BatchNorm that follows (no second pass over the output for the statistics).
 FUSE_BN_STATS = True
 
+# Rows layers whose input is cat[expand(per-cloud columns), per-point columns] (sv_dgcnn_partseg.py:115-121): the per-cloud block of a
+# binarized layer is counted once per cloud and added to the per-point block's counts (identical outputs, _ops.BinLinearCloud) instead of
+# being repeated over the N points - conv8 of sv_dgcnn_partseg: 1 600 of 2 144 columns.
+SPLIT_BROADCAST = True
+
 # Classifier heads (a binarized dense layer + BatchNorm + activation over batch-size rows): one fused pass forward, two backward
 # (csrc/head.hip) instead of ~12 launch-bound kernels per layer.
 FUSE_HEAD = True

@@ -48,7 +48,8 @@ __global__ __launch_bounds__(1024, 4) void binlinear_i8_fwd_kernel(const float* 
                                                                    const float* __restrict__ bias, int64_t M, int K, int O, int Kp,
                                                                    float* __restrict__ y, uint32_t* __restrict__ x_sign32,
                                                                    uint32_t* __restrict__ x_nz32, uint32_t* __restrict__ x_ste32,
-                                                                   double* __restrict__ col_sums) {
+                                                                   double* __restrict__ col_sums, const float* __restrict__ cloud_n,
+                                                                   int64_t rows_per_cloud) {
     constexpr int OT = 128 * NTW;                      // output channels per workgroup
     extern __shared__ __attribute__((aligned(16))) unsigned char bl_lds[];     // [At | Bt | pw]: one array (cdna guide: no second __shared__ object)
     int8_t* At = reinterpret_cast<int8_t*>(bl_lds);                             // [BM][LDA]
@@ -176,6 +177,21 @@ __global__ __launch_bounds__(1024, 4) void binlinear_i8_fwd_kernel(const float* 
         __syncthreads();      // At / Bt / pw are rewritten by the next chunk
     }
 #undef SVNET_BL_LOAD_A
+    // ---- (optional) the columns of the layer's input that are constant over a cloud's rows (a broadcast half of a concatenation,
+    // sv_dgcnn_partseg.py:115-118 `repeat` + `cat`, sv_pointnet_cls.py:43-52 `expand_as` + `svcat`) are not multiplied row by row: their
+    // integer count n_cloud[b, o] - the same XNOR-popcount sum over THEIR columns, computed once per cloud - is added to the per-point
+    // count here.  The sum of the two counts IS the count over the full row: outputs and batch statistics identical to the full product.
+    if (cloud_n) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int o = min(o0 + 32 * (NTW * wc + t) + r, O - 1);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t m = min(m0 + 32 * wr + (i & 3) + 8 * (i >> 2) + 4 * h, M - 1);
+                acc[t][i] += (int)cloud_n[(m / rows_per_cloud) * O + o];
+            }
+        }
+    }
     // ---- epilogue: y = count * scale + bias  (the expression of binlinear_fwd_kernel: identical outputs)
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
@@ -236,10 +252,12 @@ extern "C" int svnet_binweight_pack_i8(const float* W, int64_t O, int64_t K, int
     return SVNET_OK;
 }
 
-extern "C" int svnet_binlinear_i8_fwd_f32(const float* x, int64_t ldx, const float* beta, const int8_t* w_i8, const float* scale,
-                                          const float* bias, int64_t M, int64_t K, int64_t O, float* y, uint64_t* x_sign, uint64_t* x_nz,
-                                          uint64_t* x_ste, double* col_sums, void* stream) {
+static int binlinear_i8_launch(const float* x, int64_t ldx, const float* beta, const int8_t* w_i8, const float* scale,
+                               const float* bias, int64_t M, int64_t K, int64_t O, float* y, uint64_t* x_sign, uint64_t* x_nz,
+                               uint64_t* x_ste, double* col_sums, const float* cloud_n, int64_t rows_per_cloud, void* stream) {
     SVNET_REQUIRE(x && beta && w_i8 && scale && y, SVNET_E_ARG, "svnet_binlinear_i8_fwd_f32: null pointer");
+    SVNET_REQUIRE(!cloud_n || (rows_per_cloud > 0 && M % rows_per_cloud == 0), SVNET_E_ARG,
+                  "svnet_binlinear_i8_cloud_fwd_f32: rows_per_cloud must divide M");
     SVNET_REQUIRE(M >= 0 && K > 0 && O > 0 && ldx >= K, SVNET_E_ARG, "svnet_binlinear_i8_fwd_f32: bad sizes");
     const bool any = x_sign || x_nz || x_ste, all = x_sign && x_nz && x_ste;
     SVNET_REQUIRE(!any || all, SVNET_E_ARG, "svnet_binlinear_i8_fwd_f32: pass all three saved planes or none");
@@ -258,11 +276,26 @@ extern "C" int svnet_binlinear_i8_fwd_f32(const float* x, int64_t ldx, const flo
     if (!ok) return SVNET_E_LAUNCH;
 #define SVNET_BL_LAUNCH(NTW_)                                                                                                          \
     hipLaunchKernelGGL((binlinear_i8_fwd_kernel<NTW_>), grid, dim3(1024), lds, (hipStream_t)stream, x, ldx, beta, w_i8, scale, bias, M, (int)K, \
-                       (int)O, Kp, y, reinterpret_cast<uint32_t*>(x_sign), reinterpret_cast<uint32_t*>(x_nz), reinterpret_cast<uint32_t*>(x_ste), col_sums)
+                       (int)O, Kp, y, reinterpret_cast<uint32_t*>(x_sign), reinterpret_cast<uint32_t*>(x_nz), reinterpret_cast<uint32_t*>(x_ste), col_sums, \
+                       cloud_n, rows_per_cloud > 0 ? rows_per_cloud : 1)
     if (ntw == 1) SVNET_BL_LAUNCH(1);
     else if (ntw == 2) SVNET_BL_LAUNCH(2);
     else SVNET_BL_LAUNCH(4);
 #undef SVNET_BL_LAUNCH
     SVNET_CHECK_LAUNCH("binlinear_i8_fwd_kernel");
     return SVNET_OK;
+}
+
+extern "C" int svnet_binlinear_i8_fwd_f32(const float* x, int64_t ldx, const float* beta, const int8_t* w_i8, const float* scale,
+                                          const float* bias, int64_t M, int64_t K, int64_t O, float* y, uint64_t* x_sign, uint64_t* x_nz,
+                                          uint64_t* x_ste, double* col_sums, void* stream) {
+    return binlinear_i8_launch(x, ldx, beta, w_i8, scale, bias, M, K, O, y, x_sign, x_nz, x_ste, col_sums, nullptr, 0, stream);
+}
+
+extern "C" int svnet_binlinear_i8_cloud_fwd_f32(const float* x, int64_t ldx, const float* beta, const int8_t* w_i8, const float* scale,
+                                                const float* bias, int64_t M, int64_t K, int64_t O, float* y, uint64_t* x_sign,
+                                                uint64_t* x_nz, uint64_t* x_ste, double* col_sums, const float* cloud_n,
+                                                int64_t rows_per_cloud, void* stream) {
+    SVNET_REQUIRE(cloud_n, SVNET_E_ARG, "svnet_binlinear_i8_cloud_fwd_f32: null cloud counts");
+    return binlinear_i8_launch(x, ldx, beta, w_i8, scale, bias, M, K, O, y, x_sign, x_nz, x_ste, col_sums, cloud_n, rows_per_cloud, stream);
 }

@@ -6,7 +6,7 @@ reference models/sv_dgcnn_partseg.py:18-128; composition only.
 from .sv_layers import *
 from .utils.sv_util import *
 from .sv_layers import batch_norm_act, _ACT_LEAKY
-from .. import _ops
+from .. import _ops, config
 
 
 def _round8(v, divisor=8):
@@ -27,6 +27,17 @@ class _ConvBNAct(nn.Sequential):
         y = self[0].forward_rows(rows) if isinstance(self[0], Conv1d) else \
             _ops.FpLinear.apply(rows, self[0].weight.view(self[0].out_channels, -1), None)
         return batch_norm_act(self[1], y, _ACT_LEAKY, 0.2)
+
+    def forward_rows_split(self, x_cloud, x_point):
+        """The layer on cat[expand(x_cloud [B,Kc]), x_point [B,N,Kp]] (the reference's `repeat` + `cat`, sv_dgcnn_partseg.py:115-121)
+        WITHOUT the concatenation: a binarized layer adds the per-cloud block's integer counts - B rows - to the per-point block's
+        (_ops.BinLinearCloud: identical outputs); anything else concatenates."""
+        conv = self[0]
+        if config.SPLIT_BROADCAST and isinstance(conv, Conv1d) and conv.binary and x_point.is_cuda and x_point.dim() == 3:
+            y = _ops.BinLinearCloud.apply(x_cloud, x_point, conv.weight, conv.beta, conv.scale, conv.training)
+            return batch_norm_act(self[1], y, _ACT_LEAKY, 0.2)
+        B, N = x_point.shape[:2]
+        return self.forward_rows(torch.cat([x_cloud.unsqueeze(1).expand(B, N, x_cloud.shape[-1]), x_point], dim=-1))
 
     def forward(self, x):                                            # x: [B,C,N]
         return self.forward_rows(x.transpose(1, 2)).transpose(1, 2).contiguous()
@@ -90,8 +101,8 @@ class SV_DGCNN_PSEG(nn.Module):
         # the head on channel-LAST rows [B,N,head_in] = [glob | pooled | lab (one row per cloud, broadcast) | fine]: the same columns
         # in the same order as the reference's channel-first cat (sv_dgcnn_partseg.py:117-121), written once
         percloud = torch.cat([glob, pooled.transpose(-1, -2), lab], dim=1).transpose(1, 2)          # [B,1,1600]
-        rows = torch.cat([percloud.expand(B, N, percloud.shape[-1]), fine], dim=-1)                  # [B,N,head_in]
-        rows = self.dp1(self.conv8.forward_rows(rows))
+        # (the 1 600 per-cloud columns are NOT repeated over the N points: conv8 counts them once per cloud, _ops.BinLinearCloud)
+        rows = self.dp1(self.conv8.forward_rows_split(percloud.reshape(B, -1), fine))
         rows = self.dp2(self.conv9.forward_rows(rows))
         rows = self.conv10.forward_rows(rows)
         w = self.conv11.weight.view(self.conv11.out_channels, -1)

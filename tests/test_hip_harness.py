@@ -392,3 +392,45 @@ def test_gate_mlp_on_rows_matches_pooling_then_mlp(B, R, Cin, H, Ov, hip_device)
     for x_, y_, name in zip(res[1], res[0], ("gate", "ds", "dW0", "dW2")):
         err = float((x_ - y_).abs().max() / y_.abs().max().clamp_min(1e-30))
         assert err < 1e-5, (name, err)
+
+
+@pytest.mark.parametrize("training", [True, False], ids=["train", "eval"])
+@pytest.mark.parametrize("B,N,Kc,Kp,O", [(4, 300, 200, 96, 64), (2, 2048, 1600, 544, 256), (3, 64, 70, 33, 40), (32, 32, 1600, 544, 256)])
+def test_binarized_layer_with_per_cloud_columns_equals_the_layer_on_the_concatenation(B, N, Kc, Kp, O, training, hip_device):
+    """_ops.BinLinearCloud - the binarized layer on cat[expand(x_cloud), x_point] (sv_dgcnn_partseg.py:115-121: conv8 on the repeated
+    per-cloud feature + the per-point feature; sv_layers.py:55-78) with the per-cloud columns counted once per cloud - against
+    _ops.BinLinear on the materialised concatenation: outputs BIT-identical (the two integer counts add up to the full row's), the
+    saved decision planes identical, every gradient to 2e-5 of its largest element (the per-cloud block's are sums in another order)."""
+    from svnet_amd import _ops
+    from tests.decisions import tapped
+    g = torch.Generator().manual_seed(7 + Kc)
+    K = Kc + Kp
+    xc = torch.round(torch.randn(B, Kc, generator=g) * 3) / 3            # exact zeros / values on the STE clip among them
+    xp = torch.randn(B, N, Kp, generator=g)
+    xp[0, 1, ::5] = 0.0
+    W = torch.randn(O, K, 1, generator=g)
+    W[1, ::9] = 0.0
+    beta = torch.randn(1, K, 1, generator=g) * 0.3
+    beta[0, ::4] = 0.0
+    scale = torch.rand(1, O, 1, generator=g) + 0.5
+    w = torch.randn(B, N, O, generator=g).to(hip_device)
+    res = {}
+    for split in (True, False):
+        leaves = [t.clone().to(hip_device).requires_grad_(True) for t in (xc, xp, W, beta, scale)]
+        c, p, Wd, bd, sd = leaves
+        with tapped() as tap:
+            if split:
+                y = _ops.BinLinearCloud.apply(c, p, Wd, bd, sd, training)
+            else:
+                rows = torch.cat([c.unsqueeze(1).expand(B, N, Kc), p], dim=-1)
+                y = _ops.BinLinear.apply(rows, Wd, bd, sd, None, training)
+        (y * w).sum().backward()
+        torch.cuda.synchronize()
+        planes = [pl.cpu() for pl in tap["signs"][-1][3]]
+        res[split] = dict(y=y.detach().cpu(), planes=planes, g=[t.grad.cpu() for t in leaves])
+    assert torch.equal(res[True]["y"], res[False]["y"])
+    for a, b in zip(res[True]["planes"], res[False]["planes"]):
+        assert torch.equal(a, b)
+    for name, a, b in zip(("x_cloud", "x_point", "W", "beta", "scale"), res[True]["g"], res[False]["g"]):
+        assert a.shape == b.shape and torch.isfinite(a).all(), name
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-6), (name, float((a - b).abs().max()), float(b.abs().max()))

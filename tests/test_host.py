@@ -40,7 +40,8 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.svnet_version() == _lib.ABI_VERSION == 407
+    header_abi = int(re.search(r"#define SVNET_ABI_VERSION (\d+)", header).group(1))
+    assert L.svnet_version() == _lib.ABI_VERSION == header_abi          # library, binding and header speak the same ABI
     assert L.svnet_knn_workspace_bytes(2, 8, 3) >= (2 * 8 * 3 + 2 * 8) * 4
 
 
