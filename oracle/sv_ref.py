@@ -164,6 +164,12 @@ def _forced_signs(t, dec, name, mag=None):
             both = torch.cat([(td.abs() / thr)[ds], ((td.abs() - STE_CLIP).abs() / (thr + dec.tau * STE_CLIP))[dm]])
             entry["largest_margin"] = float(both.max())
             entry["uncertified"] = int((both > 1.0).sum())
+            if entry["uncertified"]:      # what the worst one looked like (diagnostic: value, its threshold, the threshold's noise share)
+                w = int(both.argmax())
+                tv = torch.cat([td.abs()[ds], (td.abs() - STE_CLIP).abs()[dm]])[w]
+                th = torch.cat([thr.expand_as(td)[ds], (thr + dec.tau * STE_CLIP).expand_as(td)[dm]])[w]
+                entry["worst"] = {"distance_from_the_edge": float(tv), "threshold": float(th), "tau": dec.tau, "noise_factor": dec.noise_factor,
+                                  "rms_of_the_layer": float(rms.mean())}
         dec.log.append(entry)
     return sgn.to(t.dtype), ste.to(t.dtype)
 

@@ -22,6 +22,14 @@ def cpu_share():
     return max(1, n)
 
 
+def _default_threads():
+    import torch
+    return torch.get_num_threads()
+
+
+DEFAULT_THREADS = _default_threads()        # torch's own choice (the logical CPU count), before pytest_configure narrows it
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     import torch
