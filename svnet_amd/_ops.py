@@ -1182,6 +1182,39 @@ class Pool(torch.autograd.Function):
         return dx, None, None
 
 
+class PoolMaxParts(torch.autograd.Function):
+    """max over the points of cat[a, b] along the channels, computed from the two PARTS where they lie (the maximum of a concatenation is
+    the concatenation of the maxima): a [B,N,Ca], b [B,N,Cb] -> [B, Ca+Cb] - sv_dgcnn_partseg.py:107-108 pools svfuse3's [B,N,1016]
+    feature at once, so that concatenation is never built (nor its gradient sliced).  One decision record, as the pooled concatenation's."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _hip(a, b)
+        a, b = _f32c(a), _f32c(b)
+        B, N, Ca = a.shape
+        Cb = b.shape[-1]
+        out = torch.empty((B, Ca + Cb), dtype=torch.float32, device=a.device)
+        _, arg_a = pool_raw(a, B, N, Ca, 0, out=out[:, :Ca])
+        _, arg_b = pool_raw(b, B, N, Cb, 0, out=out[:, Ca:])
+        ctx.save_for_backward(arg_a, arg_b)
+        if TAP is not None:
+            TAP["pools"].append(torch.cat([arg_a, arg_b], dim=1))
+        ctx.meta = (B, N, Ca, Cb)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, N, Ca, Cb = ctx.meta
+        arg_a, arg_b = ctx.saved_tensors
+        g = _f32c(g)
+        ga, gb = g[:, :Ca].contiguous(), g[:, Ca:].contiguous()
+        da = torch.empty((B, N, Ca), dtype=torch.float32, device=g.device)
+        db = torch.empty((B, N, Cb), dtype=torch.float32, device=g.device)
+        call("svnet_pool_bwd_f32", _p(ga), _p(arg_a), B, N, Ca, 0, _p(da), _stream())
+        call("svnet_pool_bwd_f32", _p(gb), _p(arg_b), B, N, Cb, 0, _p(db), _stream())
+        return da, db
+
+
 class PoolMaxMean(torch.autograd.Function):
     """cat(max, mean) over one axis of x (the global pooling of the classifiers, sv_dgcnn_cls.py:72-74): the two reductions
     share the backward pass, so the gradient of x is written once instead of written twice and added."""

@@ -95,7 +95,9 @@ class SV_DGCNN_PSEG(nn.Module):
         fine = self.svfuse1(x)                                        # [B,N,cs+3cv]
         x = self.conv5(x)
         pooled = self.svfuse2(self.conv6(svpool(x, dim=1, keepdim=True)))          # [B,1,emb/2]
-        glob = _ops.Pool.apply(self.svfuse3(x), 1, 0).unsqueeze(-1)                 # max over points -> [B,emb,1]
+        # max over the points of cat[s, Vector2Scalar(v)] = cat of the two parts' maxima: the [B,N,1016] concatenation is never built
+        s5, sv5 = self.svfuse3.parts(x)
+        glob = _ops.PoolMaxParts.apply(s5, sv5).unsqueeze(-1)                      # [B,emb,1]
 
         lab = self.conv7(l.view(B, -1, 1))                            # [B,64,1]
         # the head on channel-LAST rows [B,N,head_in] = [glob | pooled | lab (one row per cloud, broadcast) | fine]: the same columns

@@ -422,6 +422,12 @@ class SVFuse(nn.Module):
         if self.trans_back:
             s_v, trans = self.v2s(v)
             return torch.cat([s, s_v], dim=-1), trans
+        lin = self.v2s.linear
+        if (config.FUSE_V2S_CAT and torch.is_tensor(s) and torch.is_tensor(v) and s.is_cuda and lin.weight.shape[0] == 3 and v.shape[-1] <= 768
+                and s.shape[:-1] == v.shape[:-2] and s.dim() >= 2):
+            # the concatenation written in place by the Vector2Scalar kernel (no [.., 3C] intermediate, no cat pass; its backward reads the
+            # Vector2Scalar columns of the gradient where they lie) - as SVBlock does for its linear1 input
+            return _ops.V2SCat.apply(s, v, lin.weight, lin.scale if lin.bw else None, self.training)
         return torch.cat([s, self.v2s(v)], dim=-1)
 
 

@@ -147,8 +147,10 @@ def _train_step_case(case, hip_device, corrupt=None):
     dec64 = decisions_of(tap, model=dmodel)
     dec64.value_record = {"knn": [], "signs": [], "pools": [], "acts": {}}
     lo64, ls64, Pg64 = oracle_step(model, binary, k, x, l, y, dec64, torch.float64)
+    def truth_copy():        # (the certificate pops the recorded float64 values as it goes: every fp32 run gets its own lists)
+        return {k_: (list(v_) if isinstance(v_, list) else dict(v_)) for k_, v_ in dec64.value_record.items()}
     dec = decisions_of(tap, model=dmodel)
-    dec.truth = dec64.value_record
+    dec.truth = truth_copy()
     if tag in WIDER_CERTIFICATE:
         # ppseg_fp_b16 (sv_pointnet_partseg: a 1e-7 input change moves its logits by 4e-4) decides its global max over the points among
         # ~20 near-ties in 65 504 values that carry amplified rounding noise, and their gaps spread up to the certificate's threshold:
@@ -171,7 +173,7 @@ def _train_step_case(case, hip_device, corrupt=None):
         torch.set_num_threads(DEFAULT_THREADS)
         try:
             dec = decisions_of(tap, model=dmodel)
-            dec.truth = dec64.value_record
+            dec.truth = truth_copy()
             if tag in WIDER_CERTIFICATE:
                 dec.noise_factor = 30.0
             lo, ls, Pg = oracle_step(model, binary, k, x, l, y, dec)
