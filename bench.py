@@ -282,6 +282,10 @@ def dgcnn_cls_legs(args, model, x, train, work, torch, _lib):
             stages["knn_gather_forward"] = {
                 "bound": "hbm", "algorithmic_bytes": KNN_GATHER_STAGE_BYTES, "time_ms": round(t_stage * 1e3, 4),
                 "knn_only_ms": round(t_knn_only * 1e3, 4),
+                # the stage with the k-NN term split out (VERDICT r4 #6c): the four fused gather + SVBlock + pooling kernels alone
+                # against the same bytes - what the gather half reaches; the exact k-NN's own floor is profiles/r05_knn_floor.txt
+                "gather_block_pool_ms": round((t_stage - t_knn_only) * 1e3, 4),
+                "frac_without_knn": round(KNN_GATHER_STAGE_BYTES / (t_stage - t_knn_only) / 1e9 / HBM_PEAK_GBS, 4),
                 "achieved": round(KNN_GATHER_STAGE_BYTES / t_stage / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(KNN_GATHER_STAGE_BYTES / t_stage / 1e9 / HBM_PEAK_GBS, 4),
                 "what": "SURVEY §8(d) bytes of the 4 k-NN + gather stages / (svnet_knn_f32 + 3 x svnet_knn_sv_f32 + xyzblock_fwd + 3 x edgeblock_fwd); the fused "

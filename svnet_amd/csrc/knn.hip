@@ -998,10 +998,16 @@ __global__ __launch_bounds__(512, 4) void knn_mf8_kernel(const float* __restrict
         for (int tt = 0; tt < NTL; ++tt) dacc[a][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     float av[2], bv[NTL], avn[2], bvn[NTL];
+#if SVNET_KNN_ABL == 4   // diagnostic build (tools/knn_floor.sh): NO distance phase - the hand-over and the selection on zero inner products
+    const int nks_run = 0;
+    (void)nks;
+#else
+    const int nks_run = nks;
+#endif
     SVNET_KNN_DMA4(0); SVNET_KNN_DMA4(1); SVNET_KNN_DMA4(2);
     SVNET_KNN_STEP_END();                                                // k-steps 0 and 1 have landed
     SVNET_KNN_OPERANDS(0, av, bv);
-    for (int s = 0; s < nks; ++s) {
+    for (int s = 0; s < nks_run; ++s) {
         SVNET_KNN_DMA4(s + 3);
         __builtin_amdgcn_sched_barrier(0);
         SVNET_KNN_PRODUCTS_HALF(av, bv, 0);
@@ -1040,7 +1046,7 @@ __global__ __launch_bounds__(512, 4) void knn_mf8_kernel(const float* __restrict
             for (int t = 0; t < T; ++t) acc[2 * pass + r][t] = rows[(2 * wave + r) * LDS_H + 64 * t + lane];
         }
     }
-#if SVNET_KNN_ABL >= 1   // diagnostic builds: no selection
+#if SVNET_KNN_ABL >= 1 && SVNET_KNN_ABL <= 3   // diagnostic builds: no selection
     {
         float sm = 0.f;
 #pragma unroll
@@ -1153,6 +1159,9 @@ static int knn_impl(const float* x, const float* x2, int64_t split, int64_t B, i
                                       (size_t)SVNET_KNN_TP * ((size_t)C | 1) * sizeof(float), st, x, B, N, C, xx_mode, xT, xx, x2, split, mf8 ? C8 : C);
     else hipLaunchKernelGGL(knn_prep_kernel<false>, dim3(svnet_grid(B * N, 64)), dim3(64), 0, st, x, B, N, C, sb, sn, sc, xx_mode, xT, xx, x2, split, mf8 ? C8 : C);
     SVNET_CHECK_LAUNCH("knn_prep_kernel");
+#if SVNET_KNN_ABL == 5   // diagnostic build: the table preparation alone
+    return SVNET_OK;
+#endif
     const int n = (int)N, c = (int)C;
     if (N <= 64) launch_main<1, 8>(xT, xx, B, n, c, k, idx_out, st);
     else if (N <= 128) launch_main<2, 8>(xT, xx, B, n, c, k, idx_out, st);
