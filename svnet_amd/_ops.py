@@ -618,6 +618,12 @@ class BinLinear(torch.autograd.Function):
         if need_w and beside.on:                              # helper-stream form: the weight gradient is issued first, beside the input gradient
             with beside:
                 dW, dsc = wgrad()
+        # TrainStep (svnet_amd.train) gathers the parameter gradients ONCE, after the backward: a big layer's weight-gradient chain then goes
+        # to the TAIL of the side stream, unjoined (_Deferred) - the main stream carries on with what the layer in front waits for (dx) and
+        # the chain fills the chip under the launch-bound kernels that follow it there (conv5 of the classifier: gate MLP, mean / Vector2Scalar
+        # backward, the next layer's prelude)
+        defer = (need_w and not beside.on and need_x and ctx.training and DEFERRED.active and config.DEFER_ROWS_WGRAD
+                 and M >= config.TWO_STREAM_MIN_ROWS and DEFERRED.first_use(W, sc))
         dbuf = None
         if need_x:
             # (otherwise) the input gradient FIRST: its column sums (dL/dbeta, a sliced accumulator) are then totalled by the weight-gradient
@@ -631,7 +637,15 @@ class BinLinear(torch.autograd.Function):
             dx = dx.view(xshape)
             dbeta = dbuf[:K].view(bshape)
         pending = need_x and ctx.training                     # the slices of dbuf still have to be added up
-        if need_w and not beside.on:
+        if defer:
+            main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+            ready = main.record_event()                       # (g2, the planes and dbuf's slices are complete on this stream)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                dW, dsc = wgrad(dbuf, K)                      # (its epilogue launch also totals dL/dbeta: a parameter gradient, like dW)
+            DEFERRED.keep.append((g2, x_sign, x_nz, W, sc, dbuf, dW, dsc))
+            pending = False
+        elif need_w and not beside.on:
             dW, dsc = wgrad(dbuf if pending else None, K if pending else 0)
             pending = False
         if pending:
@@ -1444,6 +1458,7 @@ class GlobalMaxMeanPoolBNV(torch.autograd.Function):
         with torch.cuda.stream(side):
             call("svnet_vtail_bwd_f32", _p(v3), _p(mean2), _p(invstd2), _p(g2), _p(b2), _p(gate2), _p(w_eff), _p(g[:, Ca:]), _p(g[:, Ct + Ca:]),
                  2 * Ct, _p(arg_b), B, N, C, _p(red2), _p(dgate) if gate2 is not None else None, _p(gxb), _p(g5), _stream())
+            gate_done = side.record_event()
             call("svnet_vbn_bwd_apply_f32", _p(g5), _p(v3), _p(mean2), _p(invstd2), _p(g2), _p(b2), _p(gate2), _p(red2), N, P, C,
                  int(training), _p(dv), _stream())
             if sczf is not None:
@@ -1454,10 +1469,17 @@ class GlobalMaxMeanPoolBNV(torch.autograd.Function):
                 dWz, dscz = gxb[:3 * C].view(3, C), None
         call("svnet_bn_pool_bwd_f32", _p(g), _p(g[:, Ct:]), 2 * Ct, _p(arg_a), _p(y2), _p(mean1), _p(invstd1), _p(g1), _p(b1), B, N, Ca,
              act, slope, int(training), _p(red1), _p(dy), _stream())
-        main.wait_stream(side)
-        for t in (dv, g5, dWz, dscz):
-            if t is not None:
-                t.record_stream(main)
+        if DEFERRED.active and config.DEFER_ROWS_WGRAD:
+            # inside a TrainStep the main stream only waits for what IT goes on to read - the gate's gradient (vtail_bwd) - and carries on
+            # with linear1's backward while VectorBN's apply pass runs: dv is consumed on the side stream (linear2's backward runs where its
+            # forward ran), the parameter gradients (VectorBN's, svfuse's) are taken once, after the step's one join (_Deferred)
+            main.wait_event(gate_done)
+            DEFERRED.keep.append((v3, g5, dv, red2, gxb, dWz, dscz, g, mean2, invstd2, gate2, w_eff, arg_b))
+        else:
+            main.wait_stream(side)
+            for t in (dv, g5, dWz, dscz):
+                if t is not None:
+                    t.record_stream(main)
         # forward args: y, v_lin, gate, g1, b1, rm1, rv1, g2, b2, rm2, rv2, Wz, scz, training, act, slope, nbt1, nbt2, eps, momentum
         return (dy, dv.view(vshape), dgate.view(gshape) if gate2 is not None else None, red1[Ca:2 * Ca], red1[:Ca], None, None,
                 red2[C:2 * C], red2[:C], None, None, dWz, dscz, None, None, None, None, None, None, None)

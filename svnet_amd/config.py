@@ -54,6 +54,10 @@ FUSE_HEAD = True
 # (svnet_amd._ops._Deferred); False = every backward joins before it returns
 DEFER_WGRAD = True
 VEC_EARLY = True
+# ... and so do the weight-gradient chains of the big rows layers (conv5.linear1 of the classifier: 111 + 11 us at the tail of the side
+# stream instead of in front of the launch-bound end of conv5's backward), and the classifier tail's vector half no longer holds the main
+# stream back (it waits for the gate's gradient only)
+DEFER_ROWS_WGRAD = True
 # (round 4 measured the gate's chain - per-cloud mean of s, MLP - of an SVBlock on rows on the side stream behind linear2's product:
 #  4.62 ms against 4.57 - 4.60 with the gate on the main stream; the switch and its code path are gone.)
 # sign-weight products with many rows and more than 128 columns go to the LDS-tiled rows kernel from this K on (it needs K >= 64)
