@@ -643,7 +643,7 @@ class BinLinear(torch.autograd.Function):
             with torch.cuda.stream(side):
                 side.wait_event(ready)
                 dW, dsc = wgrad(dbuf, K)                      # (its epilogue launch also totals dL/dbeta: a parameter gradient, like dW)
-            DEFERRED.keep.append((g2, x_sign, x_nz, W, sc, dbuf, dW, dsc))
+            DEFERRED.keep.append((g2, x_sign, x_nz, W, sc, dbuf))     # (NOT the returned gradients: see EdgeBlock.backward)
             pending = False
         elif need_w and not beside.on:
             dW, dsc = wgrad(dbuf if pending else None, K if pending else 0)
@@ -1450,15 +1450,17 @@ class GlobalMaxMeanPoolBNV(torch.autograd.Function):
         dev = g.device
         F = torch.float32
         dy = torch.empty((B, N, Ca), dtype=F, device=dev) if ctx.needs_input_grad[0] else None
-        dv = torch.empty((P, 3, C), dtype=F, device=dev)
-        g5 = torch.empty((P, 3, C), dtype=F, device=dev)
         red1, red2, dgate, gxb = _zeros_pool(dev, ((_sliced_len(2 * Ca),), F), ((_sliced_len(2 * C),), F), ((B, C), F), ((_sliced_len(3 * C),), F))
         main, side = torch.cuda.current_stream(dev), _side_stream(dev)
         side.wait_stream(main)
         with torch.cuda.stream(side):
+            # (allocated ON the side stream: every kernel that touches them runs there - this pass, VectorBN's apply pass, linear2's backward,
+            #  which autograd runs where its forward ran - so the allocator may hand their blocks on as soon as they are freed; allocated on the
+            #  main stream, dv's block went back to the MAIN stream's pool while linear2's products were still reading it)
+            dv = torch.empty((P, 3, C), dtype=F, device=dev)
+            g5 = torch.empty((P, 3, C), dtype=F, device=dev)
             call("svnet_vtail_bwd_f32", _p(v3), _p(mean2), _p(invstd2), _p(g2), _p(b2), _p(gate2), _p(w_eff), _p(g[:, Ca:]), _p(g[:, Ct + Ca:]),
                  2 * Ct, _p(arg_b), B, N, C, _p(red2), _p(dgate) if gate2 is not None else None, _p(gxb), _p(g5), _stream())
-            gate_done = side.record_event()
             call("svnet_vbn_bwd_apply_f32", _p(g5), _p(v3), _p(mean2), _p(invstd2), _p(g2), _p(b2), _p(gate2), _p(red2), N, P, C,
                  int(training), _p(dv), _stream())
             if sczf is not None:
@@ -1469,17 +1471,12 @@ class GlobalMaxMeanPoolBNV(torch.autograd.Function):
                 dWz, dscz = gxb[:3 * C].view(3, C), None
         call("svnet_bn_pool_bwd_f32", _p(g), _p(g[:, Ct:]), 2 * Ct, _p(arg_a), _p(y2), _p(mean1), _p(invstd1), _p(g1), _p(b1), B, N, Ca,
              act, slope, int(training), _p(red1), _p(dy), _stream())
-        if DEFERRED.active and config.DEFER_ROWS_WGRAD:
-            # inside a TrainStep the main stream only waits for what IT goes on to read - the gate's gradient (vtail_bwd) - and carries on
-            # with linear1's backward while VectorBN's apply pass runs: dv is consumed on the side stream (linear2's backward runs where its
-            # forward ran), the parameter gradients (VectorBN's, svfuse's) are taken once, after the step's one join (_Deferred)
-            main.wait_event(gate_done)
-            DEFERRED.keep.append((v3, g5, dv, red2, gxb, dWz, dscz, g, mean2, invstd2, gate2, w_eff, arg_b))
-        else:
-            main.wait_stream(side)
-            for t in (dv, g5, dWz, dscz):
-                if t is not None:
-                    t.record_stream(main)
+        # (main waits for the WHOLE vector half here.  Waiting for the gate's gradient only - all the main stream goes on to read - measured
+        #  4.219 against 4.227 ms and a captured step's first replay then held a stale weight gradient of linear2: not kept)
+        main.wait_stream(side)
+        for t in (dWz, dscz):
+            if t is not None:
+                t.record_stream(main)
         # forward args: y, v_lin, gate, g1, b1, rm1, rv1, g2, b2, rm2, rv2, Wz, scz, training, act, slope, nbt1, nbt2, eps, momentum
         return (dy, dv.view(vshape), dgate.view(gshape) if gate2 is not None else None, red1[Ca:2 * Ca], red1[:Ca], None, None,
                 red2[C:2 * C], red2[:C], None, None, dWz, dscz, None, None, None, None, None, None, None)
