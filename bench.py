@@ -200,10 +200,10 @@ def cpu_baseline(wl, sample_b=None, timed=3, threads=None):
 # ----------------------------------------------------------------------------- roofline legs
 
 def measured_traffic(kernel_key):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes of THIS build (profiles/r04_pmc_traffic.json, written by
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes of THIS build (profiles/r05_pmc_traffic.json, written by
     tools/make_traffic_json.py from separate FETCH_SIZE / WRITE_SIZE passes; units and gfx950 corrections as MI355X_MICROARCH.md
     prescribes: 2 x FETCH_SIZE + WRITE_SIZE)."""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)

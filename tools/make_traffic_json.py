@@ -20,5 +20,5 @@ for r in rows:
     if key_of(r[0]) and r[fi] and r[wi]:
         f, w = float(r[fi]) * 1e3, float(r[wi]) * 1e3
         out["kernels"][key_of(r[0])] = {"kernel": r[0], "launches": int(r[1]), "fetch_size_bytes": f, "write_size_bytes": w, "traffic_bytes": 2 * f + w}
-json.dump(out, open(sys.argv[3] if len(sys.argv) > 3 else "profiles/r04_pmc_traffic.json", "w"), indent=1)
+json.dump(out, open(sys.argv[3] if len(sys.argv) > 3 else "profiles/r05_pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out["kernels"].get("edgeblock_bwd_conv4")))
