@@ -473,6 +473,21 @@ class _Deferred:
 DEFERRED = _Deferred()
 
 
+class defer_rows_wgrad:
+    """`with _ops.defer_rows_wgrad():` around the FORWARD of a big rows layer marks it: inside a TrainStep its weight-gradient chain may go
+    to the tail of the side stream (BinLinear.backward).  Opt-in per call site, because it only pays where launch-bound kernels follow the
+    layer's backward on the main stream (conv5 of sv_dgcnn_cls: 4.29 -> 4.23 ms); applied to every rows layer it cost sv_pointnet_cls
+    --binary 0.38 ms per step (5.66 -> 6.04: the deferred products queue up in front of the next blocks' vector paths)."""
+    on = False
+
+    def __enter__(self):
+        self.prev, defer_rows_wgrad.on = defer_rows_wgrad.on, True
+        return self
+
+    def __exit__(self, *exc):
+        defer_rows_wgrad.on = self.prev
+
+
 def _binweight(W, scale, i8=False):
     """{w_sign, w_nz (row-major 64-bit plane words), w_b (+-1/0 values), w_eff (scale*sign(W)), w_i8 (int8 MFMA operand, only for
     callers that ask: i8=True)} of a bw layer's weight [O,K].  The re-pack closure kept by the cache holds the parameters WEAKLY."""
@@ -597,6 +612,7 @@ class BinLinear(torch.autograd.Function):
         if need_grad:
             ctx.save_for_backward(W, sc, w_b, *planes)
         ctx.meta = (M, K, O, KW, x.shape, beta.shape, scale.shape, bias is not None, W_in.shape)
+        ctx.defer_ok = defer_rows_wgrad.on
         return y.view(x.shape[:-1] + (O,))
 
     @staticmethod
@@ -622,7 +638,7 @@ class BinLinear(torch.autograd.Function):
         # to the TAIL of the side stream, unjoined (_Deferred) - the main stream carries on with what the layer in front waits for (dx) and
         # the chain fills the chip under the launch-bound kernels that follow it there (conv5 of the classifier: gate MLP, mean / Vector2Scalar
         # backward, the next layer's prelude)
-        defer = (need_w and not beside.on and need_x and ctx.training and DEFERRED.active and config.DEFER_ROWS_WGRAD
+        defer = (need_w and not beside.on and need_x and ctx.training and DEFERRED.active and config.DEFER_ROWS_WGRAD and ctx.defer_ok
                  and M >= config.TWO_STREAM_MIN_ROWS and DEFERRED.first_use(W, sc))
         dbuf = None
         if need_x:

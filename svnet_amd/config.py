@@ -55,7 +55,8 @@ FUSE_HEAD = True
 DEFER_WGRAD = True
 VEC_EARLY = True
 # ... and so do the weight-gradient chains of the big rows layers (conv5.linear1 of the classifier: 111 + 11 us at the tail of the side
-# stream instead of in front of the launch-bound end of conv5's backward): 4.29 -> 4.23 ms (profiles/r05_ab_defer_rows.log)
+# stream instead of in front of the launch-bound end of conv5's backward): 4.29 -> 4.23 ms (profiles/r05_ab_defer_rows.log).  Opt-in per
+# call site (_ops.defer_rows_wgrad): on every rows layer of sv_pointnet_cls it cost 0.38 ms per step
 DEFER_ROWS_WGRAD = True
 # (round 4 measured the gate's chain - per-cloud mean of s, MLP - of an SVBlock on rows on the side stream behind linear2's product:
 #  4.62 ms against 4.57 - 4.60 with the gate on the main stream; the switch and its code path are gone.)

@@ -59,7 +59,8 @@ class SV_DGCNN_CLS(nn.Module):
                     and bn.training == bn2.training
                     and _ops.GlobalMaxMeanPoolBNV.supported(x5[0].shape[0], x5[0].shape[1], self.conv5.linear1.out_features, fz.weight.shape[1])):
                 # ... and so do VectorBN, the gate, svfuse's Vector2Scalar and the pooling of ITS half, in one pass over linear2's product
-                y5, v_lin, gate = self.conv5.forward_pretail(x5)
+                with _ops.defer_rows_wgrad():                # (its weight-gradient chain may leave the backward's critical path)
+                    y5, v_lin, gate = self.conv5.forward_pretail(x5)
                 pooled = _ops.GlobalMaxMeanPoolBNV.apply(
                     y5, v_lin, gate, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn2.weight, bn2.bias, bn2.running_mean,
                     bn2.running_var, fz.weight, fz.scale if fz.bw else None, bn.training, _ACT_LEAKY, self.conv5.relu.negative_slope,
@@ -67,7 +68,8 @@ class SV_DGCNN_CLS(nn.Module):
                 h = self.dp1(linear_bn_act(self.linear1, self.bn1, pooled, _ACT_LEAKY, 0.2))
                 h = self.dp2(linear_bn_act(self.linear2, self.bn2, h, _ACT_LEAKY, 0.2))
                 return _ops.FpLinear.apply(h, self.linear3.weight, self.linear3.bias)
-            y5, v5 = self.conv5.forward_prebn(x5)
+            with _ops.defer_rows_wgrad():
+                y5, v5 = self.conv5.forward_prebn(x5)
             sv5 = self.svfuse.v2s(v5)
             nbt = bn.num_batches_tracked if bn.training else None
             pooled = _ops.GlobalMaxMeanPoolBN.apply(y5, sv5, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, _ACT_LEAKY,
