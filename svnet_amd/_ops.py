@@ -1763,7 +1763,8 @@ class EdgeBlock(torch.autograd.Function):
         def build():
             out = {"wv": torch.empty((2 * Ov + 6, Cv), **f32), "scv": torch.empty((2 * Ov + 6,), **f32),
                    "w_sign": torch.empty((Os, 5), dtype=torch.int64, device=dev), "w_nz": torch.empty((Os, 5), dtype=torch.int64, device=dev),
-                   "beta_perm": torch.empty((5 * 64,), **f32), "wbt": torch.empty((320 * ((Os + 15) // 16 * 16),), dtype=torch.int16, device=dev)}
+                   "beta_perm": torch.empty((5 * 64,), **f32), "wbt": torch.empty((320 * ((Os + 15) // 16 * 16),), dtype=torch.int16, device=dev),
+                   "w_dense": torch.zeros((1,), dtype=torch.int32, device=dev)}       # 1 = no exact zero in W1 (set by the prepare kernel)
 
             def rebuild():                       # (holds the parameters weakly: a dead model's entry is dropped by _PlaneCache._stale())
                 ps = [r() for r in refs]
@@ -1773,7 +1774,7 @@ class EdgeBlock(torch.autograd.Function):
                 call("svnet_edgeblock_prepare_vec_f32", _p(_f32c(W2p.detach())), _p(_f32c(sc2p.detach()).reshape(-1)), _p(_f32c(Wzp.detach())),
                      _p(_f32c(sczp.detach()).reshape(-1)), Ov, Cv, _p(out["wv"]), _p(out["scv"]), _stream())
                 call("svnet_edgeblock_prepare_f32", _p(_f32c(W1p.detach())), _p(_f32c(beta1p.detach())), Os, Cs, Cv, _p(out["w_sign"]), _p(out["w_nz"]),
-                     _p(out["beta_perm"]), _stream())
+                     _p(out["beta_perm"]), _p(out["w_dense"]), _stream())
                 call("svnet_edgeblock_wbt_bf16", _p(out["w_sign"]), _p(out["w_nz"]), Os, _p(out["wbt"]), _stream())
             rebuild()
             return out, rebuild
@@ -1810,6 +1811,7 @@ class EdgeBlock(torch.autograd.Function):
         d.Cs, d.Cv, d.Os, d.Ov = Cs, Cv, Os, Ov
         d.s, d.v, d.idx, d.zz, d.ut = _p(s), _p(v), _p(idx), _p(zz), _p(ut)
         d.w_sign, d.w_nz, d.beta_perm = _p(w_sign), _p(w_nz), _p(beta_perm)
+        d.w_dense = _p(packed["w_dense"]) if config.EDGE_DENSE_WEIGHTS else None
         d.n_max, d.n_min, d.slot_max, d.slot_min = _p(n_max), _p(n_min), _p(slot_max), _p(slot_min)
         d.mv, d.mvn, d.stat_n, d.stat_v, d.gate_sum = _p(mv), _p(mvn), _p(stat_n), _p(stat_v), _p(gate_sum)
         # kept for the backward instead of any fp32 edge tensor: the integer sum n (2 B per edge-channel) and the sign /

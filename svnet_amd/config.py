@@ -79,3 +79,7 @@ FUSE_VBN_STATS = False
 # SVBlock on rows, narrow s (the PointNet callers): the per-cloud mean of s the gate MLP starts from is formed inside the MLP's launch
 # (_ops.GateMLPRows) instead of by a pooling pass of two launches in front of it
 GATE_MEAN_INSIDE = True
+
+# Fused forward edge kernels: when no weight of linear1 is exactly 0 (a device-side flag the packing kernel sets) the popcount products skip
+# the weights' non-zero plane: the edge's own non-zero count is one scalar per edge, a word costs xor + and + bcnt instead of five instructions
+EDGE_DENSE_WEIGHTS = True
