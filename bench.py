@@ -611,6 +611,9 @@ def rank_main(args):
     import torch.distributed as dist
     backend = "gloo" if selftest else "nccl"
     collective = world > 1 or args.force_collective
+    if not selftest and local >= torch.cuda.device_count():          # (device_count() does not initialise the GPU)
+        print("bench.py: rank %d wants cuda:%d but this node shows %d GPU(s)" % (rank, local, torch.cuda.device_count()), file=sys.stderr)
+        return 2
     if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1 and "MASTER_PORT" not in os.environ:
