@@ -47,7 +47,7 @@ int svnet_slices_sum_f64(double* buf, int64_t L, void* stream);
  * changes its required length (200: sliced accumulators, SVNET_SLICED_LEN; 400: this header; 401: the totals of a sliced accumulator are
  * written by its consumer, svnet_slices_sum_*; 402: GX of svnet_v2s_bwd_*, gw of svnet_xyzblock_bwd_f32 and col_sum of svnet_gemm_f32 are sliced accumulators; 403: svnet_binweight_grad_f32 takes sliced inputs).  svnet_version() returns the value the
  * library was BUILT with: a caller compiled against another header must refuse to run (svnet_amd/_lib.py does).                   */
-#define SVNET_ABI_VERSION 410
+#define SVNET_ABI_VERSION 411
 int svnet_version(void);
 const char* svnet_last_error(void);
 
@@ -471,7 +471,9 @@ int svnet_pool_maxmean_fwd_f32(const float* x, int64_t outer, int64_t R, int64_t
  * svnet_pool_maxmean_fwd_f32 (R >= 256).  The values equal pooling svnet_bn_act_fwd_f32's output bit for bit.                     */
 int svnet_bn_pool_fwd_f32(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                           int64_t outer, int64_t R, int64_t inner, int act, float slope, float* out_max, float* out_mean,
-                          int64_t out_ld, int32_t* argmax, void* workspace, size_t workspace_bytes, void* stream);
+                          int64_t out_ld, int32_t* argmax, void* workspace, size_t workspace_bytes,
+                          int workspace_zeroed /* != 0: the first outer*inner*8 bytes of the workspace (the arg-max keys) are zero already */,
+                          void* stream);
 /* Its backward from the POOLED gradients (gmax, gmean: rows of stride g_ld): the gradient of the activated tensor,
  * (r == argmax ? gmax : 0) + gmean / R, is formed on the fly.  red [2*inner] (caller zero-fills) = [dbeta | dgamma];
  * dy [outer*R, inner] (may be NULL) the gradient of y, with the batch-statistic terms when train_stats.                           */
@@ -492,7 +494,8 @@ size_t svnet_vtail_workspace_bytes(int64_t B, int64_t N, int64_t C);
 int svnet_vtail_fwd_f32(const float* v, const double* sums, float eps, float momentum, float* mean, float* invstd,
                         float* running_mean, float* running_var, long long* nbt, const float* gamma, const float* beta,
                         const float* gate, const float* w_eff, int64_t B, int64_t N, int64_t C, float* out_max, float* out_mean,
-                        int64_t out_ld, int32_t* argmax, void* workspace, size_t workspace_bytes, void* stream);
+                        int64_t out_ld, int32_t* argmax, void* workspace, size_t workspace_bytes,
+                        int workspace_zeroed /* != 0: the first B*3C*8 bytes (the arg-max keys) are zero already */, void* stream);
 /* Its backward up to VectorBN's batch sums, from the POOLED gradients (gmax / gmean: rows of stride g_ld): the gradient of the scalars,
  * (point == argmax ? gmax : 0) + gmean / N, is formed on the fly, Vector2Scalar's backward runs in registers.  Outputs: g5 [B*N, 3, C] =
  * dL/d(VectorBN's output), to be handed to svnet_vbn_bwd_apply_f32 as its `g` together with `red`; red = SLICED accumulator of 2C floats

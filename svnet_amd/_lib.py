@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVNET_DIAG_LIB") or os.path.join(_HERE, "libsvnet_hip.so")    # (SVNET_DIAG_LIB: an ablation build, tools/ only)
 _lib = None
-ABI_VERSION = 410       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
+ABI_VERSION = 411       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
 
 c_p = ctypes.c_void_p
 c_i64 = ctypes.c_int64
@@ -193,13 +193,13 @@ SIGNATURES = {
     "svnet_pool_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64, c_int]),
     "svnet_pool_fwd_f32": (c_int, [c_p, c_i64, c_i64, c_i64, c_int, c_p, c_i64, c_p, c_p, c_sz, c_p]),
     "svnet_pool_maxmean_fwd_f32": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_p, c_sz, c_p]),
-    "svnet_bn_pool_fwd_f32": (c_int, [c_p] * 5 + [c_i64] * 3 + [c_int, c_f, c_p, c_p, c_i64, c_p, c_p, c_sz, c_p]),
+    "svnet_bn_pool_fwd_f32": (c_int, [c_p] * 5 + [c_i64] * 3 + [c_int, c_f, c_p, c_p, c_i64, c_p, c_p, c_sz, c_int, c_p]),
     "svnet_bn_pool_bwd_f32": (c_int, [c_p, c_p, c_i64] + [c_p] * 6 + [c_i64] * 3 + [c_int, c_f, c_int, c_p, c_p, c_p]),
     "svnet_pool_bwd_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_int, c_p, c_p]),
     "svnet_pool_mean_bwd_add_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
     "svnet_pool_maxmean_bwd_f32": (c_int, [c_p, c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p]),
     "svnet_vtail_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
-    "svnet_vtail_fwd_f32": (c_int, [c_p, c_p, c_f, c_f] + [c_p] * 9 + [c_i64] * 3 + [c_p, c_p, c_i64, c_p, c_p, c_sz, c_p]),
+    "svnet_vtail_fwd_f32": (c_int, [c_p, c_p, c_f, c_f] + [c_p] * 9 + [c_i64] * 3 + [c_p, c_p, c_i64, c_p, c_p, c_sz, c_int, c_p]),
     "svnet_vtail_bwd_f32": (c_int, [c_p] * 9 + [c_i64, c_p] + [c_i64] * 3 + [c_p] * 5),
     "svnet_act_fwd_f32": (c_int, [c_p, c_i64, c_int, c_p, c_p]),
     "svnet_act_bwd_f32": (c_int, [c_p, c_p, c_i64, c_int, c_p, c_p]),

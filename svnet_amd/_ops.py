@@ -1347,10 +1347,10 @@ class GlobalMaxMeanPoolBN(torch.autograd.Function):
             arg_b = pool_maxmean_raw(b, B, N, Cb, out[:, Ca:C], out[:, C + Ca:])
             arg_b.record_stream(main)
         nb = L.svnet_pool_workspace_bytes(B, N, Ca, 0) + L.svnet_pool_workspace_bytes(B, N, Ca, 1)
-        ws = torch.empty((nb,), dtype=torch.uint8, device=y.device)
+        ws = _zeros((nb,), torch.uint8, y.device)          # (zero keys from the step's one fill: no memset launch in front of the pass)
         arg_a = torch.empty((B, Ca), dtype=torch.int32, device=y.device)
         call("svnet_bn_pool_fwd_f32", _p(y2), _p(mean), _p(invstd), _p(gamma), _p(beta), B, N, Ca, act, slope, _p(out), _p(out[:, C:]),
-             2 * C, _p(arg_a), _p(ws), nb, _stream())
+             2 * C, _p(arg_a), _p(ws), nb, 1, _stream())
         main.wait_stream(side)
         ctx.save_for_backward(y2, mean, invstd, gamma, beta, arg_a, arg_b)
         if TAP is not None:
@@ -1424,7 +1424,7 @@ class GlobalMaxMeanPoolBNV(torch.autograd.Function):
         invstd2 = torch.empty((C,), dtype=torch.float32, device=dev)
         arg_b = torch.empty((B, Cb), dtype=torch.int32, device=dev)
         nbw = L.svnet_vtail_workspace_bytes(B, N, C)
-        wsb = torch.empty((nbw,), dtype=torch.uint8, device=dev)
+        wsb = _zeros((nbw,), torch.uint8, dev)              # (zero keys from the step's one fill: no memset launch in front of the pass)
         rec, _FUSED_VSTATS = _FUSED_VSTATS, None
         main, side = torch.cuda.current_stream(dev), _side_stream(dev)
         side.wait_stream(main)                                          # (the gate and the statistics buffers come from this stream)
@@ -1440,12 +1440,12 @@ class GlobalMaxMeanPoolBNV(torch.autograd.Function):
                 call("svnet_bn_eval_stats_f32", _p(rm2), _p(rv2), C, eps, _p(mean2), _p(invstd2), _stream())
             call("svnet_vtail_fwd_f32", _p(v3), _p(sums), eps, momentum, _p(mean2), _p(invstd2), _p(rm2) if training else None,
                  _p(rv2) if training else None, _p(nbt2) if training else None, _p(g2), _p(b2), _p(gate2), _p(w_eff), B, N, C,
-                 _p(out[:, Ca:]), _p(out[:, Ct + Ca:]), 2 * Ct, _p(arg_b), _p(wsb), nbw, _stream())
+                 _p(out[:, Ca:]), _p(out[:, Ct + Ca:]), 2 * Ct, _p(arg_b), _p(wsb), nbw, 1, _stream())
         nb = L.svnet_pool_workspace_bytes(B, N, Ca, 0) + L.svnet_pool_workspace_bytes(B, N, Ca, 1)
-        ws = torch.empty((nb,), dtype=torch.uint8, device=dev)
+        ws = _zeros((nb,), torch.uint8, dev)
         arg_a = torch.empty((B, Ca), dtype=torch.int32, device=dev)
         call("svnet_bn_pool_fwd_f32", _p(y2), _p(mean1), _p(invstd1), _p(g1), _p(b1), B, N, Ca, act, slope, _p(out), _p(out[:, Ct:]),
-             2 * Ct, _p(arg_a), _p(ws), nb, _stream())
+             2 * Ct, _p(arg_a), _p(ws), nb, 1, _stream())
         main.wait_stream(side)
         ctx.save_for_backward(y2, mean1, invstd1, g1, b1, arg_a, arg_b, v3, mean2, invstd2, g2, b2, gate2, w_eff, Wzc, sczf)
         if TAP is not None:

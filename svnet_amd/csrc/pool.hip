@@ -523,7 +523,8 @@ extern "C" int svnet_pool_maxmean_fwd_f32(const float* x, int64_t outer, int64_t
  * tensor is not written).  Outputs and workspace as svnet_pool_maxmean_fwd_f32.                                                   */
 extern "C" int svnet_bn_pool_fwd_f32(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                                      int64_t outer, int64_t R, int64_t inner, int act, float slope, float* out_max, float* out_mean,
-                                     int64_t out_ld, int32_t* argmax, void* workspace, size_t workspace_bytes, void* stream) {
+                                     int64_t out_ld, int32_t* argmax, void* workspace, size_t workspace_bytes, int workspace_zeroed,
+                                     void* stream) {
     SVNET_REQUIRE(y && mean && invstd && gamma && beta && out_max && out_mean && argmax && outer > 0 && R >= 256 && inner > 0 &&
                       out_ld >= inner, SVNET_E_ARG, "svnet_bn_pool_fwd_f32: bad arguments (R >= 256)");
     const int64_t total = outer * inner;
@@ -537,8 +538,10 @@ extern "C" int svnet_bn_pool_fwd_f32(const float* y, const float* mean, const fl
     hipStream_t st = (hipStream_t)stream;
     unsigned long long* keys = (unsigned long long*)workspace;
     float* part = (float*)((char*)workspace + key_bytes);
-    hipError_t e = hipMemsetAsync(keys, 0, key_bytes, st);
-    SVNET_REQUIRE(e == hipSuccess, SVNET_E_LAUNCH, "svnet_bn_pool_fwd_f32: memset failed");
+    if (!workspace_zeroed) {      // (a caller that hands over zero-filled memory - one fill per step for everything - saves this launch)
+        hipError_t e = hipMemsetAsync(keys, 0, key_bytes, st);
+        SVNET_REQUIRE(e == hipSuccess, SVNET_E_LAUNCH, "svnet_bn_pool_fwd_f32: memset failed");
+    }
     hipLaunchKernelGGL(bn_pool_split_kernel, dim3((unsigned)chunks, (unsigned)outer), dim3(pool_col_block(inner)), 0, st, y, mean, invstd, gamma, beta, act,
                        slope, R, inner, rpc, keys, part, total);
     SVNET_CHECK_LAUNCH("bn_pool_split_kernel");

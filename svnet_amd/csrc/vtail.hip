@@ -424,7 +424,8 @@ extern "C" size_t svnet_vtail_workspace_bytes(int64_t B, int64_t N, int64_t C) {
 extern "C" int svnet_vtail_fwd_f32(const float* v, const double* sums, float eps, float momentum, float* mean, float* invstd,
                                    float* running_mean, float* running_var, long long* nbt, const float* gamma, const float* beta,
                                    const float* gate, const float* w_eff, int64_t B, int64_t N, int64_t C, float* out_max,
-                                   float* out_mean, int64_t out_ld, int32_t* argmax, void* workspace, size_t workspace_bytes, void* stream) {
+                                   float* out_mean, int64_t out_ld, int32_t* argmax, void* workspace, size_t workspace_bytes,
+                                   int workspace_zeroed, void* stream) {
     SVNET_REQUIRE(v && mean && invstd && gamma && beta && w_eff && out_max && out_mean && argmax && workspace, SVNET_E_ARG,
                   "svnet_vtail_fwd_f32: null pointer");
     SVNET_REQUIRE(B > 0 && B <= 65535 && N > 0 && N < (1 << 30) && C > 0 && out_ld >= 3 * C, SVNET_E_ARG, "svnet_vtail_fwd_f32: bad sizes");
@@ -436,8 +437,10 @@ extern "C" int svnet_vtail_fwd_f32(const float* v, const double* sums, float eps
     const int64_t total = B * 3 * C;
     unsigned long long* keys = (unsigned long long*)workspace;
     float* part = (float*)((char*)workspace + (size_t)total * 8);
-    hipError_t e = hipMemsetAsync(keys, 0, (size_t)total * 8, st);
-    SVNET_REQUIRE(e == hipSuccess, SVNET_E_LAUNCH, "svnet_vtail_fwd_f32: memset failed");
+    if (!workspace_zeroed) {
+        hipError_t e = hipMemsetAsync(keys, 0, (size_t)total * 8, st);
+        SVNET_REQUIRE(e == hipSuccess, SVNET_E_LAUNCH, "svnet_vtail_fwd_f32: memset failed");
+    }
     VtStats s{};
     s.sums = sums; s.mean_out = mean; s.invstd_out = invstd; s.rmean = running_mean; s.rvar = running_var; s.nbt = nbt;
     s.mean_in = mean; s.invstd_in = invstd; s.eps = eps; s.momentum = momentum;
