@@ -672,12 +672,13 @@ class BinLinear(torch.autograd.Function):
         return dx, dW, dbeta, dsc, dbias, None
 
 
-def _binweight_cols(W, scale, k0, k1, i8=False):
-    """_binweight() of the column block W[:, k0:k1] of a bw layer's weight [O,K] (a contiguous copy is packed; cached per
-    (parameter, block) like the whole-matrix forms and re-packed with them when the parameter changes)."""
+def _binweight_cols(W, scale, ranges, i8=False):
+    """_binweight() of the columns W[:, a:b] for (a, b) in `ranges`, side by side, of a bw layer's weight [O,K] (a contiguous copy is
+    packed; cached per (parameter, column set) like the whole-matrix forms and re-packed with them when the parameter changes)."""
     import weakref
     O, dev = W.shape[0], W.device
-    Kb = k1 - k0
+    ranges = tuple((int(a), int(b)) for a, b in ranges if b > a)
+    Kb = sum(b - a for a, b in ranges)
     w_ref, s_ref = weakref.ref(W), (None if scale is None else weakref.ref(scale))
 
     def build():
@@ -689,13 +690,14 @@ def _binweight_cols(W, scale, k0, k1, i8=False):
             Wp = w_ref()
             if Wp is None or (s_ref is not None and s_ref() is None):
                 return
-            Wc = Wp.detach().reshape(O, -1)[:, k0:k1].contiguous()
+            W2 = Wp.detach().reshape(O, -1)
+            Wc = (W2[:, ranges[0][0]:ranges[0][1]] if len(ranges) == 1 else torch.cat([W2[:, a:b] for a, b in ranges], dim=1)).contiguous()
             call("svnet_binweight_prepare_f32", _p(Wc), None, O, Kb, _p(out["w_sign"]), _p(out["w_nz"]), _p(out["w_b"]), None, _stream())
             if out["w_i8"] is not None:
                 call("svnet_binweight_pack_i8", _p(Wc), O, Kb, _p(out["w_i8"]), _stream())
         rebuild()
         return out, rebuild
-    return PLANES.get("bwcols:%d:%d:%d" % (k0, k1, int(i8)), (W,) if scale is None else (W, scale), build)
+    return PLANES.get("bwcols:%s:%d" % (",".join("%d-%d" % r for r in ranges), int(i8)), (W,) if scale is None else (W, scale), build)
 
 
 def _cloud_planes_as_rows(planes, B, N, K):
@@ -727,49 +729,54 @@ class BinLinearCloud(torch.autograd.Function):
     input / weight gradients are the usual products over Kp columns, the per-cloud block's are products over B rows."""
 
     @staticmethod
-    def forward(ctx, x_cloud, x_point, W, beta, scale, training=True):
+    def forward(ctx, x_cloud, x_point, W, beta, scale, training=True, cloud_at=0):
+        """cloud_at: first column of the per-cloud block in the layer's row (0: sv_dgcnn_partseg's conv8, whose per-cloud features come first;
+        512: conv_fuse.linear1 of sv_pointnet_cls, cat[s, expand(pooled s), Vector2Scalar(v)]); the per-point columns keep their order."""
         global _FUSED_COLSUMS
         _hip(x_cloud, x_point, W, beta, scale)
         ctx.training = bool(training)
         B, N, Kp = x_point.shape
         Kc = x_cloud.shape[-1]
+        k0 = int(cloud_at)
         xp = _f32c(x_point).reshape(B * N, Kp)
         xc = _f32c(x_cloud).reshape(B, Kc)
         W_in, Wc = W, _f32c(W).reshape(W.shape[0], -1)
         O, K = Wc.shape
-        if K != Kc + Kp:
-            raise ValueError("BinLinearCloud: weight has %d columns, inputs %d + %d" % (K, Kc, Kp))
+        if K != Kc + Kp or not 0 <= k0 <= Kp:
+            raise ValueError("BinLinearCloud: weight has %d columns, inputs %d + %d (cloud block at %d)" % (K, Kc, Kp, k0))
         M = B * N
         dev = xp.device
         need_grad = any(ctx.needs_input_grad)
         sc, bt = _f32c(scale).view(-1), _f32c(beta).view(-1)
-        pk_c = _binweight_cols(W_in, scale, 0, Kc)
-        pk_p = _binweight_cols(W_in, scale, Kc, K, i8=True)
+        bt_c = bt[k0:k0 + Kc]
+        bt_p = bt[Kc:] if k0 == 0 else torch.cat([bt[:k0], bt[k0 + Kc:]])
+        pk_c = _binweight_cols(W_in, scale, [(k0, k0 + Kc)])
+        pk_p = _binweight_cols(W_in, scale, [(0, k0), (k0 + Kc, K)], i8=True)
         keep = need_grad or TAP is not None
         pl_c = [torch.empty(((B + 63) // 64, Kc), dtype=torch.int64, device=dev) for _ in range(3)] if keep else [None] * 3
         pl_p = [torch.empty(((M + 63) // 64, Kp), dtype=torch.int64, device=dev) for _ in range(3)] if keep else [None] * 3
         # the per-cloud block: integer counts of the B rows (scale 1: the values are exact integers in fp32)
         ones = torch.ones((O,), dtype=torch.float32, device=dev)
         n_cloud = torch.empty((B, O), dtype=torch.float32, device=dev)
-        call("svnet_binlinear_fwd_f32", _p(xc), Kc, _p(bt), _p(pk_c["w_sign"]), _p(pk_c["w_nz"]), _p(ones), None, B, Kc, O, _p(n_cloud),
+        call("svnet_binlinear_fwd_f32", _p(xc), Kc, _p(bt_c), _p(pk_c["w_sign"]), _p(pk_c["w_nz"]), _p(ones), None, B, Kc, O, _p(n_cloud),
              _p(pl_c[0]), _p(pl_c[1]), _p(pl_c[2]), _stream())
         y = torch.empty((M, O), dtype=torch.float32, device=dev)
         sums = _zeros((_sliced_len(2 * O),), torch.float64, dev) if (training and config.FUSE_BN_STATS and K <= 46340) else None
-        call("svnet_binlinear_i8_cloud_fwd_f32", _p(xp), Kp, _p(bt[Kc:]), _p(pk_p["w_i8"]), _p(sc), None, M, Kp, O, _p(y),
+        call("svnet_binlinear_i8_cloud_fwd_f32", _p(xp), Kp, _p(bt_p), _p(pk_p["w_i8"]), _p(sc), None, M, Kp, O, _p(y),
              _p(pl_p[0]), _p(pl_p[1]), _p(pl_p[2]), _p(sums), _p(n_cloud), N, _stream())
         _FUSED_COLSUMS = (y, y._version, sums) if sums is not None else None
         if TAP is not None:      # the planes of the full [M, K] rows, as the layer over the materialised concatenation would have recorded them
-            full = [torch.cat([a, b], dim=1).contiguous() for a, b in zip(_cloud_planes_as_rows(pl_c, B, N, Kc), pl_p)]
+            full = [torch.cat([b[:, :k0], a, b[:, k0:]], dim=1).contiguous() for a, b in zip(_cloud_planes_as_rows(pl_c, B, N, Kc), pl_p)]
             TAP["signs"].append(("rows", M, K, full))
         if need_grad:
             ctx.save_for_backward(Wc, sc, pk_c["w_b"], pk_p["w_b"], *pl_c, *pl_p)
-        ctx.meta = (B, N, Kc, Kp, O, x_cloud.shape, x_point.shape, beta.shape, scale.shape, W_in.shape)
+        ctx.meta = (B, N, Kc, Kp, O, x_cloud.shape, x_point.shape, beta.shape, scale.shape, W_in.shape, k0)
         return y.view(B, N, O)
 
     @staticmethod
     def backward(ctx, g):
         Wc, sc, wb_c, wb_p, cs, cz, cq, ps, pz, pq = ctx.saved_tensors
-        B, N, Kc, Kp, O, cshape, pshape, bshape, sshape, wshape = ctx.meta
+        B, N, Kc, Kp, O, cshape, pshape, bshape, sshape, wshape, k0 = ctx.meta
         K, M = Kc + Kp, B * N
         dev = g.device
         g2 = _f32c(g).reshape(M, O)
@@ -790,15 +797,21 @@ class BinLinearCloud(torch.autograd.Function):
         else:       # eval: bare sign() has zero gradient (sv_layers.py:38-39)
             dxp = torch.zeros((M, Kp), dtype=torch.float32, device=dev)
             dxc = torch.zeros((B, Kc), dtype=torch.float32, device=dev)
-        dbeta = torch.cat([dbuf_c[:Kc], dbuf_p[:Kp]]).view(bshape)
+        dbeta = torch.cat([dbuf_p[:k0], dbuf_c[:Kc], dbuf_p[k0:Kp]]).view(bshape)
         if need_w:
             # GX[o, k] = sum_m g[m,o] x_b[m,k]: the per-cloud columns from the B summed rows, the per-point columns from all rows
-            GX = _zeros((O, K), torch.float32, dev)
-            gemm(Kc, O, B, a_planes=(cs, cz), B=gc, b_rs=O, b_cs=1, C=GX, ldc=1, c_cs=K, accumulate=True)
-            gemm(Kp, O, M, a_planes=(ps, pz), B=g2, b_rs=O, b_cs=1, C=GX[:, Kc:], ldc=1, c_cs=K, accumulate=True)
+            if k0 == 0:
+                GX = _zeros((O, K), torch.float32, dev)
+                gemm(Kc, O, B, a_planes=(cs, cz), B=gc, b_rs=O, b_cs=1, C=GX, ldc=1, c_cs=K, accumulate=True)
+                gemm(Kp, O, M, a_planes=(ps, pz), B=g2, b_rs=O, b_cs=1, C=GX[:, Kc:], ldc=1, c_cs=K, accumulate=True)
+            else:       # (the per-point columns are not one run of the row: products into their own buffers, one small cat)
+                GXc, GXp = _zeros((O, Kc), torch.float32, dev), _zeros((O, Kp), torch.float32, dev)
+                gemm(Kc, O, B, a_planes=(cs, cz), B=gc, b_rs=O, b_cs=1, C=GXc, ldc=1, c_cs=Kc, accumulate=True)
+                gemm(Kp, O, M, a_planes=(ps, pz), B=g2, b_rs=O, b_cs=1, C=GXp, ldc=1, c_cs=Kp, accumulate=True)
+                GX = torch.cat([GXp[:, :k0], GXc, GXp[:, k0:]], dim=1)
             dW, dsc = _binweight_grad(GX, Wc, sc, O, K, ctx.training)
             dW, dsc = dW.view(wshape), dsc.view(sshape)
-        return dxc.view(cshape), dxp.view(pshape), dW, dbeta, dsc, None
+        return dxc.view(cshape), dxp.view(pshape), dW, dbeta, dsc, None, None
 
 
 class BinLinearBNAct(torch.autograd.Function):

@@ -360,6 +360,41 @@ class SVBlock(nn.Module):
         (the classifier's tail, _ops.GlobalMaxMeanPoolBNV).  Rows path only; v_lin may still be in flight on the side stream."""
         return self._forward_rows(x, prebn=True, pretail=True)
 
+    def forward_cloud_s(self, s_point, s_cloud, v):
+        """The block on (cat[s_point, expand(s_cloud)], v) - the reference's `svcat([x, expand_as(pooled)])` of sv_pointnet_cls.py:50-52 -
+        WITHOUT the concatenation of the scalar halves: linear1 counts the per-cloud columns once per cloud (_ops.BinLinearCloud, identical
+        outputs), the gate's mean over the rows of a broadcast column is the column.  s_point [B,N,Cp], s_cloud [B,Cc], v [B,N,3,Cv] (whole).
+        Binarized blocks on device rows only; anything else concatenates and takes forward()."""
+        lin1 = self.linear1
+        B, N, Cp = s_point.shape
+        Cc = s_cloud.shape[-1]
+        ok = (config.SPLIT_BROADCAST and lin1.bw and lin1.ba and lin1.bias is None and s_point.is_cuda and self._v2s_cat_fusable(s_point, v)
+              and lin1.in_features == Cp + Cc + 3 * v.shape[-1] and B * N >= 1024 and lin1.out_features >= 64
+              and self.gate[0].out_features <= 256 and self.gate[2].out_features <= 256)
+        if not ok:
+            return self.forward((torch.cat([s_point, s_cloud.unsqueeze(1).expand(B, N, Cc)], dim=-1), v))
+        lz = self.v2s.linear
+        two = config.TWO_STREAM_BLOCKS and B * N >= config.TWO_STREAM_MIN_ROWS
+        if two:
+            main, side = torch.cuda.current_stream(s_point.device), _ops._side_stream(s_point.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                v_lin = self.linear2(v, vstats=True)
+        # cat[s_point, Vector2Scalar(v)] in place + the per-cloud mean of s_point (one consumer of s_point in the autograd graph)
+        cat_pt, mean_pt = _ops.V2SCat.apply(s_point, v, lz.weight, lz.scale if lz.bw else None, self.training, B)
+        v_scale = _ops.GateMLP.apply(torch.cat([mean_pt, s_cloud], dim=-1), self.gate[0].weight, self.gate[2].weight)
+        y = _ops.BinLinearCloud.apply(s_cloud, cat_pt, lin1.weight, lin1.beta, lin1.scale, self.training, Cp)
+        s_out = batch_norm_act(self.bn1, y, _ACT_LEAKY, self.relu.negative_slope)
+        if two:
+            side.wait_stream(main)                       # (the gate came from the main stream)
+            with torch.cuda.stream(side):
+                v_out = self.bn2(v_lin, gate=v_scale)
+            main.wait_stream(side)
+            v_out.record_stream(main)
+        else:
+            v_out = self.bn2(self.linear2(v, vstats=True), gate=v_scale)
+        return (s_out, v_out)
+
     def _forward_rows(self, x, prebn=False, pretail=False):
         s, v = x
         rows = s.numel() // max(s.shape[-1], 1)

@@ -37,8 +37,11 @@ class SVPointNetEncoder(nn.Module):
         x = svcat([x, _broadcast_like((g[0].unsqueeze(1), g[1].unsqueeze(1)), x)])
         x = self.conv3(self.conv2(x))
 
-        x = svcat([x, _broadcast_like(svpool(x, dim=1, keepdim=True), x)])
-        x = svpool(self.conv_fuse(x), dim=1)
+        # svcat([x, expand_as(pooled)]) -> conv_fuse (reference :50-52): the scalar halves are not concatenated - conv_fuse.linear1 counts the
+        # 512 per-cloud columns of its 2 044 once per cloud (SVBlock.forward_cloud_s); the vector halves are (Vector2Scalar mixes them per point)
+        gs, gv = svpool(x, dim=1, keepdim=True)
+        v_cat = torch.cat([x[1], gv.expand_as(x[1])], dim=-1)
+        x = svpool(self.conv_fuse.forward_cloud_s(x[0], gs.reshape(gs.shape[0], -1), v_cat), dim=1)
         return self.svfuse(x)                                         # [B,1022]
 
 

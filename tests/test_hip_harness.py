@@ -395,8 +395,9 @@ def test_gate_mlp_on_rows_matches_pooling_then_mlp(B, R, Cin, H, Ov, hip_device)
 
 
 @pytest.mark.parametrize("training", [True, False], ids=["train", "eval"])
-@pytest.mark.parametrize("B,N,Kc,Kp,O", [(4, 300, 200, 96, 64), (2, 2048, 1600, 544, 256), (3, 64, 70, 33, 40), (32, 32, 1600, 544, 256)])
-def test_binarized_layer_with_per_cloud_columns_equals_the_layer_on_the_concatenation(B, N, Kc, Kp, O, training, hip_device):
+@pytest.mark.parametrize("B,N,Kc,Kp,O,at", [(4, 300, 200, 96, 64, 0), (2, 2048, 1600, 544, 256, 0), (3, 64, 70, 33, 40, 0), (32, 32, 1600, 544, 256, 0),
+                                            (4, 256, 512, 1532, 512, 512), (3, 300, 70, 133, 64, 65)])
+def test_binarized_layer_with_per_cloud_columns_equals_the_layer_on_the_concatenation(B, N, Kc, Kp, O, at, training, hip_device):
     """_ops.BinLinearCloud - the binarized layer on cat[expand(x_cloud), x_point] (sv_dgcnn_partseg.py:115-121: conv8 on the repeated
     per-cloud feature + the per-point feature; sv_layers.py:55-78) with the per-cloud columns counted once per cloud - against
     _ops.BinLinear on the materialised concatenation: outputs BIT-identical (the two integer counts add up to the full row's), the
@@ -420,9 +421,9 @@ def test_binarized_layer_with_per_cloud_columns_equals_the_layer_on_the_concaten
         c, p, Wd, bd, sd = leaves
         with tapped() as tap:
             if split:
-                y = _ops.BinLinearCloud.apply(c, p, Wd, bd, sd, training)
-            else:
-                rows = torch.cat([c.unsqueeze(1).expand(B, N, Kc), p], dim=-1)
+                y = _ops.BinLinearCloud.apply(c, p, Wd, bd, sd, training, at)
+            else:           # (at: where the per-cloud block sits in the row - 0 = sv_dgcnn_partseg's conv8, 512 = sv_pointnet_cls's conv_fuse.linear1)
+                rows = torch.cat([p[..., :at], c.unsqueeze(1).expand(B, N, Kc), p[..., at:]], dim=-1)
                 y = _ops.BinLinear.apply(rows, Wd, bd, sd, None, training)
         (y * w).sum().backward()
         torch.cuda.synchronize()
