@@ -368,9 +368,10 @@ class SVBlock(nn.Module):
         lin1 = self.linear1
         B, N, Cp = s_point.shape
         Cc = s_cloud.shape[-1]
-        ok = (config.SPLIT_BROADCAST and lin1.bw and lin1.ba and lin1.bias is None and s_point.is_cuda and self._v2s_cat_fusable(s_point, v)
-              and lin1.in_features == Cp + Cc + 3 * v.shape[-1] and B * N >= 1024 and lin1.out_features >= 64
-              and self.gate[0].out_features <= 256 and self.gate[2].out_features <= 256)
+        binary = lin1.bw and lin1.ba
+        ok = (config.SPLIT_BROADCAST and (binary or not (lin1.bw or lin1.ba)) and lin1.bias is None and s_point.is_cuda
+              and self._v2s_cat_fusable(s_point, v) and lin1.in_features == Cp + Cc + 3 * v.shape[-1] and B * N >= 1024
+              and lin1.out_features >= 64 and self.gate[0].out_features <= 256 and self.gate[2].out_features <= 256)
         if not ok:
             return self.forward((torch.cat([s_point, s_cloud.unsqueeze(1).expand(B, N, Cc)], dim=-1), v))
         lz = self.v2s.linear
@@ -383,7 +384,14 @@ class SVBlock(nn.Module):
         # cat[s_point, Vector2Scalar(v)] in place + the per-cloud mean of s_point (one consumer of s_point in the autograd graph)
         cat_pt, mean_pt = _ops.V2SCat.apply(s_point, v, lz.weight, lz.scale if lz.bw else None, self.training, B)
         v_scale = _ops.GateMLP.apply(torch.cat([mean_pt, s_cloud], dim=-1), self.gate[0].weight, self.gate[2].weight)
-        y = _ops.BinLinearCloud.apply(s_cloud, cat_pt, lin1.weight, lin1.beta, lin1.scale, self.training, Cp)
+        if binary:
+            y = _ops.BinLinearCloud.apply(s_cloud, cat_pt, lin1.weight, lin1.beta, lin1.scale, self.training, Cp)
+        else:
+            # full precision: the product is linear in its columns - per-point columns over B*N rows, per-cloud columns over B rows,
+            # one broadcast add (the per-cloud block's gradients are then sums over each cloud's rows, formed by autograd)
+            W = lin1.weight
+            y = _ops.FpLinear.apply(cat_pt, torch.cat([W[:, :Cp], W[:, Cp + Cc:]], dim=1), None) \
+                + _ops.FpLinear.apply(s_cloud, W[:, Cp:Cp + Cc], None).unsqueeze(1)
         s_out = batch_norm_act(self.bn1, y, _ACT_LEAKY, self.relu.negative_slope)
         if two:
             side.wait_stream(main)                       # (the gate came from the main stream)
