@@ -1777,7 +1777,7 @@ class EdgeBlock(torch.autograd.Function):
             out = {"wv": torch.empty((2 * Ov + 6, Cv), **f32), "scv": torch.empty((2 * Ov + 6,), **f32),
                    "w_sign": torch.empty((Os, 5), dtype=torch.int64, device=dev), "w_nz": torch.empty((Os, 5), dtype=torch.int64, device=dev),
                    "beta_perm": torch.empty((5 * 64,), **f32), "wbt": torch.empty((320 * ((Os + 15) // 16 * 16),), dtype=torch.int16, device=dev),
-                   "w_dense": torch.zeros((1,), dtype=torch.int32, device=dev)}       # 1 = no exact zero in W1 (set by the prepare kernel)
+                   "w_dense": torch.zeros((8,), dtype=torch.int32, device=dev)}       # SVNET_EDGE_DENSE_WORDS flags: all 1 = no exact zero in W1 (the prepare kernel sets them)
 
             def rebuild():                       # (holds the parameters weakly: a dead model's entry is dropped by _PlaneCache._stale())
                 ps = [r() for r in refs]

@@ -39,6 +39,7 @@ __device__ __forceinline__ int fused_feature(int w, int b, int Cs, int Cv) {
     return b < 2 * Cv ? 2 * Cs + b * 3 + (w - 2) : -1;
 }
 
+constexpr int DENSE_WAVES = 8;     // waves of the packing kernel that look for exact zeros in W1 (SVNET_EDGE_DENSE_WORDS flags)
 // one wave per (output channel, word): lane b loads the weight of bit b, two ballots make the plane words
 __global__ __launch_bounds__(256) void edgeblock_prepare_kernel(const float* __restrict__ W, const float* __restrict__ beta, int Os, int Cs,
                                                                 int Cv, uint64_t* __restrict__ w_sign, uint64_t* __restrict__ w_nz,
@@ -56,13 +57,24 @@ __global__ __launch_bounds__(256) void edgeblock_prepare_kernel(const float* __r
         const int w = item - Os * NW;
         const int f = fused_feature(w, lane, Cs, Cv);
         beta_perm[w * 64 + lane] = f >= 0 ? beta[f] : 0.f;
-    } else if (item == Os * NW + NW && w_dense) {
-        // one more wave: is every weight of the layer non-zero?  (sign(0) = 0 makes the weights ternary in principle - sv_layers.py:44-45 -
-        // but a trained or freshly initialised layer holds no exact zero: the forward kernels then skip the non-zero plane of the weights)
+    } else if (item < Os * NW + NW + DENSE_WAVES && w_dense) {
+        // DENSE_WAVES more waves: is every weight of the layer non-zero?  (sign(0) = 0 makes the weights ternary in principle -
+        // sv_layers.py:44-45 - but a trained or freshly initialised layer holds no exact zero: the forward kernels then skip the non-zero
+        // plane of the weights.)  Wave q scans its share of W, eight loads in flight per lane, and leaves its verdict in w_dense[q]
+        // (one wave walking all 32 K weights one load at a time added 0.1 ms to every re-pack of a training step).
+        const int q = item - (Os * NW + NW);
+        const int64_t total = (int64_t)Os * K1, per = (total + DENSE_WAVES - 1) / DENSE_WAVES;
+        const int64_t e0 = q * per, e1 = min(total, e0 + per);
         bool any_zero = false;
-        for (int64_t e = lane; e < (int64_t)Os * K1; e += 64) any_zero |= (W[e] == 0.f);
+        for (int64_t e = e0 + lane; e < e1; e += 64 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = W[min(e + 64 * u, e1 - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) any_zero |= (v[u] == 0.f);
+        }
         const uint64_t z = __ballot(any_zero);
-        if (lane == 0) *w_dense = z == 0ull ? 1u : 0u;
+        if (lane == 0) w_dense[q] = z == 0ull ? 1u : 0u;
     }
 }
 
@@ -94,6 +106,14 @@ __device__ __forceinline__ void tacc(uint32_t xs, uint32_t xz, uint32_t ws, uint
 // 40 % fewer instructions in the half of the kernel that is popcounts.  Same integer, bit for bit.
 __device__ __forceinline__ void tacc_dense(uint64_t xs, uint64_t xz, uint64_t ws, int& pd) { pd += __popcll(xz & (xs ^ ws)); }
 __device__ __forceinline__ void tacc_dense(uint32_t xs, uint32_t xz, uint32_t ws, int& pd) { pd += __popc(xz & (xs ^ ws)); }
+
+__device__ __forceinline__ bool edge_weights_dense(const uint32_t* __restrict__ w_dense) {      // (wave-uniform: scalar loads)
+    if (!w_dense) return false;
+    uint32_t all = 1u;
+#pragma unroll
+    for (int q = 0; q < DENSE_WAVES; ++q) all &= w_dense[q];
+    return all == 1u;
+}
 
 // NARROW: every word has at most 32 columns in use (Cs <= 32 and 2 Cv <= 32): the popcount products run on the low halves only
 // The kernel proper.  Every table comes in as a __restrict__ parameter (the kernel below just unpacks the descriptor): with
@@ -361,7 +381,7 @@ template <int OP, bool NARROW>
 __global__ __launch_bounds__(256, (OP == 1 ? 4 : 3)) void edgeblock_fwd_kernel(FwdArgs fa) {
     const svnet_edgeblock_desc& d = fa.d;
     // (a wave-uniform branch between the two instantiations: the weights of a layer hold no exact zero in practice)
-    if (d.w_dense && *d.w_dense == 1u)
+    if (edge_weights_dense(d.w_dense))
         edgeblock_fwd_body<OP, NARROW, true>(fa, d.s, d.v, d.idx, d.zz, d.ut, d.n16, d.planes, d.n_max, d.n_min, d.slot_max, d.slot_min, d.mv, d.mvn);
     else
         edgeblock_fwd_body<OP, NARROW, false>(fa, d.s, d.v, d.idx, d.zz, d.ut, d.n16, d.planes, d.n_max, d.n_min, d.slot_max, d.slot_min, d.mv, d.mvn);
@@ -634,7 +654,7 @@ __device__ __forceinline__ void edgeblock_fwd2_body(const FwdArgs& fa) {
 
 template <int OP2>
 __global__ __launch_bounds__(256, 4) void edgeblock_fwd2_kernel(FwdArgs fa) {
-    if (fa.d.w_dense && *fa.d.w_dense == 1u) edgeblock_fwd2_body<OP2, true>(fa);      // (wave-uniform: see edgeblock_fwd_kernel)
+    if (edge_weights_dense(fa.d.w_dense)) edgeblock_fwd2_body<OP2, true>(fa);      // (wave-uniform: see edgeblock_fwd_kernel)
     else edgeblock_fwd2_body<OP2, false>(fa);
 }
 
@@ -740,7 +760,7 @@ extern "C" int svnet_edgeblock_prepare_f32(const float* W, const float* beta, in
                                            uint64_t* w_nz, float* beta_perm, uint32_t* w_dense, void* stream) {
     SVNET_REQUIRE(W && beta && w_sign && w_nz && beta_perm, SVNET_E_ARG, "svnet_edgeblock_prepare_f32: null pointer");
     SVNET_REQUIRE(Cs > 0 && Cs <= 64 && Cv > 0 && 2 * Cv <= 64 && Os > 0, SVNET_E_UNSUPPORTED, "svnet_edgeblock_prepare_f32: needs Cs <= 64, 2*Cv <= 64");
-    hipLaunchKernelGGL(edgeblock_prepare_kernel, dim3((unsigned)svnet_cdiv((Os * NW + NW + 1) * 64, 256)), dim3(256), 0, (hipStream_t)stream, W,
+    hipLaunchKernelGGL(edgeblock_prepare_kernel, dim3((unsigned)svnet_cdiv((Os * NW + NW + DENSE_WAVES) * 64, 256)), dim3(256), 0, (hipStream_t)stream, W,
                        beta, (int)Os, (int)Cs, (int)Cv, w_sign, w_nz, beta_perm, w_dense);
     SVNET_CHECK_LAUNCH("edgeblock_prepare_kernel");
     return SVNET_OK;

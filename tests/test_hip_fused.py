@@ -24,12 +24,14 @@ SHAPES = [((32, 10), (32, 10), 2, 96, 6), ((32, 10), (64, 21), 2, 80, 7), ((64, 
           ((64, 21), (128, 42), 2, 136, 20), ((64, 21), (128, 42), 1, 72, 20), ((64, 21), (128, 42), 3, 40, 8)]
 
 
-def _make(shape, dev, train, tag):
+def _make(shape, dev, train, tag, zero_w=False):
     from svnet_amd.models.sv_layers import SVBlock
     (Cs, Cv), (Os, Ov), B, N, k = shape
     in_dims, out_dims = (2 * Cs, 2 * Cv), (Os, Ov)
     params = H.module_params("SVBlock", (in_dims, out_dims, True), tag)
     params["linear1.beta"][:, ::4] = 0.0
+    if zero_w:                                         # exact zeros among the weights: sign(0) = 0 (sv_layers.py:44-45) - the general popcount path
+        params["linear1.weight"][::3, ::5] = 0.0
     with contextlib.redirect_stdout(io.StringIO()):
         blk = SVBlock(in_dims, out_dims, binary=True)
     blk.load_state_dict(params)
@@ -74,6 +76,26 @@ def test_fused_forward_matches_layerwise_and_oracle(shape, train, hip_device):
     with torch.no_grad():
         os_, ov = sv_ref.svpool(sv_ref.svblock(sv_ref.graph_feature_sv((s, v), k=k), P, "m", True, ctx))
     compare_case(got, {"out0": os_.numpy(), "out1": ov.numpy()}, 1e-4, "fused vs oracle")
+
+
+@pytest.mark.parametrize("train", [False, True], ids=["eval", "train"])
+@pytest.mark.parametrize("shape", [SHAPES[0], SHAPES[2]], ids=["narrow", "wide"])
+def test_fused_forward_with_zero_weights_takes_the_general_popcount_path(shape, train, hip_device):
+    """The forward edge kernels skip the weights' non-zero plane when the packing kernel found no exact zero in linear1.weight (a device
+    flag: config.EDGE_DENSE_WEIGHTS, csrc/edgeblock.hip) - the case of every trained or freshly initialised layer.  With zeros among the
+    weights (sign(0) = 0: ternary weights, sv_layers.py:44-45) the general path must run and agree with the layer-wise kernels bit for
+    bit on the pooled scalars (same integer counts) - and the dense path must NOT be taken (it would count the zero weights as -1)."""
+    from svnet_amd import _ops
+    blk, params, s, v, (in_dims, out_dims, B, N, k) = _make(shape, hip_device, train, "fused_zero_w", zero_w=True)
+    with torch.no_grad():
+        _, _, (fs, fv) = _run(blk, s, v, k, hip_device, True)
+        _, _, (ls, lv) = _run(blk, s, v, k, hip_device, False)
+    assert float((fs - ls).abs().max()) <= 1e-5 * float(ls.abs().max())
+    assert float((fv - lv).abs().max()) <= 1e-5 * float(lv.abs().max())
+    blk2, _, _, _, _ = _make(shape, hip_device, train, "fused_zero_w", zero_w=False)
+    with torch.no_grad():
+        _, _, (ds, _) = _run(blk2, s, v, k, hip_device, True)
+    assert float((ds - fs).abs().max()) > 1e-3 * float(fs.abs().max())      # (the zeros do change the result: the comparison above has teeth)
 
 
 @pytest.mark.parametrize("shape", SHAPES, ids=[str(i) for i in range(len(SHAPES))])
