@@ -47,7 +47,7 @@ int svnet_slices_sum_f64(double* buf, int64_t L, void* stream);
  * changes its required length (200: sliced accumulators, SVNET_SLICED_LEN; 400: this header; 401: the totals of a sliced accumulator are
  * written by its consumer, svnet_slices_sum_*; 402: GX of svnet_v2s_bwd_*, gw of svnet_xyzblock_bwd_f32 and col_sum of svnet_gemm_f32 are sliced accumulators; 403: svnet_binweight_grad_f32 takes sliced inputs).  svnet_version() returns the value the
  * library was BUILT with: a caller compiled against another header must refuse to run (svnet_amd/_lib.py does).                   */
-#define SVNET_ABI_VERSION 412
+#define SVNET_ABI_VERSION 413
 int svnet_version(void);
 const char* svnet_last_error(void);
 
@@ -201,15 +201,12 @@ typedef struct svnet_edgeblock_desc {
     /* kept for the backward (both or none): n16 [E,Os] = the integer popcount sum of every edge row, planes [E,3,5] = the
      * sign | non-zero | STE (|x+beta| <= 1.2) bit planes of the binarized edge feature in the fused bit order            */
     int16_t* n16; uint64_t* planes;
-    /* (may be NULL) the SVNET_EDGE_DENSE_WORDS flags svnet_edgeblock_prepare_f32 leaves: all 1 = no weight of the layer is exactly 0, i.e.
-     * sign(W1) is +-1 everywhere and the forward kernels may skip the weights' non-zero plane (same integer counts, 40 % fewer popcount
-     * instructions)                                                                                                                   */
+    /* (may be NULL) the flag svnet_edgeblock_wbt_bf16 leaves: 1 = no weight of the layer is exactly 0, i.e. sign(W1) is +-1 everywhere and the
+     * forward kernels may skip the weights' non-zero plane (same integer counts, 40 % fewer popcount instructions)                     */
     const uint32_t* w_dense;
 } svnet_edgeblock_desc;
-#define SVNET_EDGE_DENSE_WORDS 8
-/* w_dense (may be NULL): SVNET_EDGE_DENSE_WORDS uint32, word q = 1 when its share of W holds no exact zero (see svnet_edgeblock_desc), else 0 */
 int svnet_edgeblock_prepare_f32(const float* W, const float* beta, int64_t Os, int64_t Cs, int64_t Cv, uint64_t* w_sign,
-                                uint64_t* w_nz, float* beta_perm /*[5*64]*/, uint32_t* w_dense, void* stream);
+                                uint64_t* w_nz, float* beta_perm /*[5*64]*/, void* stream);
 /* The binarized weights of the two per-point products in one table: wv [2Ov+6, Cv] = [sign(W2[:, :Cv]) ; sign(W2[:, Cv:]) ;
  * sign(Wz[:, :Cv]) ; sign(Wz[:, Cv:])], scv [2Ov+6] = [scale2, scale2, scalez, scalez]  (ut = v.wv[:2Ov]^T*scv, zz = v.wv[2Ov:]^T*scv). */
 int svnet_edgeblock_prepare_vec_f32(const float* W2, const float* scale2, const float* Wz, const float* scalez, int64_t Ov,
@@ -266,7 +263,10 @@ typedef struct svnet_edgeblock_bwd_desc {
                                     are independent, so a caller may issue them on two streams                                   */
 } svnet_edgeblock_bwd_desc;
 /* wbt: 320 * 16*ceil(Os/16) bf16 values, [column tile (10)][k-step][lane (64)][8] (the tile kernel's B-fragment order) */
-int svnet_edgeblock_wbt_bf16(const uint64_t* w_sign, const uint64_t* w_nz, int64_t Os, uint16_t* wbt, void* stream);
+/* w_dense (may be NULL; then Cs / Cv are unused): one uint32, set to 1 when the planes show no zero weight among the columns in use
+ * (Cs bits of words 0 - 1, 2 Cv bits of words 2 - 4), else 0 - see svnet_edgeblock_desc                                                   */
+int svnet_edgeblock_wbt_bf16(const uint64_t* w_sign, const uint64_t* w_nz, int64_t Os, int64_t Cs, int64_t Cv, uint16_t* wbt,
+                             uint32_t* w_dense, void* stream);
 /* gy = Gs*lrelu'(y) at the pooled edge; red [SVNET_RED_SLICES][2*Os], redv [SVNET_RED_SLICES][2*Ov], dgate [B,Ov] accumulate (caller
  * zero-fills).  The batch sums are spread over slices (workgroup w adds to slice w % SVNET_RED_SLICES) that
  * svnet_edgeblock_bwd_coeffs_f32 adds up: 512 workgroups adding to ONE set of 2*Os + 2*Ov addresses spent more time in the memory

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVNET_DIAG_LIB") or os.path.join(_HERE, "libsvnet_hip.so")    # (SVNET_DIAG_LIB: an ablation build, tools/ only)
 _lib = None
-ABI_VERSION = 412       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
+ABI_VERSION = 413       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
 
 c_p = ctypes.c_void_p
 c_i64 = ctypes.c_int64
@@ -156,11 +156,11 @@ SIGNATURES = {
     "svnet_edgeblock_msg_stride": (c_i64, [c_i64, c_i64, c_i64]),
     "svnet_edgeblock_bwd_gather_f32": (c_int, [c_p] * 9 + [c_i64] + [c_p, c_p] + [c_i64] * 5 + [c_p, c_i64, c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_p]),
     "svnet_edgeblock_bwd_params_f32": (c_int, [c_p] * 8 + [c_i64] * 4 + [c_p] * 6 + [c_p]),
-    "svnet_edgeblock_prepare_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),
+    "svnet_edgeblock_prepare_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p]),
     "svnet_edgeblock_fwd_f32": (c_int, [ctypes.POINTER(EdgeBlockDesc), c_p]),
     "svnet_edgeblock_coeffs_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
     "svnet_edgeblock_apply_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p, c_i64, c_p, c_i64, c_p]),
-    "svnet_edgeblock_wbt_bf16": (c_int, [c_p, c_p, c_i64, c_p, c_p]),
+    "svnet_edgeblock_wbt_bf16": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "svnet_edgeblock_bwd_prelude_f32": (c_int, [c_p] * 9 + [c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_i64, c_p, c_p]),
     "svnet_edgeblock_bwd_coeffs_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "svnet_edgeblock_bwd_f32": (c_int, [ctypes.POINTER(EdgeBlockBwdDesc), c_p]),

@@ -1777,7 +1777,7 @@ class EdgeBlock(torch.autograd.Function):
             out = {"wv": torch.empty((2 * Ov + 6, Cv), **f32), "scv": torch.empty((2 * Ov + 6,), **f32),
                    "w_sign": torch.empty((Os, 5), dtype=torch.int64, device=dev), "w_nz": torch.empty((Os, 5), dtype=torch.int64, device=dev),
                    "beta_perm": torch.empty((5 * 64,), **f32), "wbt": torch.empty((320 * ((Os + 15) // 16 * 16),), dtype=torch.int16, device=dev),
-                   "w_dense": torch.zeros((8,), dtype=torch.int32, device=dev)}       # SVNET_EDGE_DENSE_WORDS flags: all 1 = no exact zero in W1 (the prepare kernel sets them)
+                   "w_dense": torch.zeros((1,), dtype=torch.int32, device=dev)}       # 1 = no exact zero in W1 (svnet_edgeblock_wbt_bf16 sets it from the planes)
 
             def rebuild():                       # (holds the parameters weakly: a dead model's entry is dropped by _PlaneCache._stale())
                 ps = [r() for r in refs]
@@ -1787,8 +1787,8 @@ class EdgeBlock(torch.autograd.Function):
                 call("svnet_edgeblock_prepare_vec_f32", _p(_f32c(W2p.detach())), _p(_f32c(sc2p.detach()).reshape(-1)), _p(_f32c(Wzp.detach())),
                      _p(_f32c(sczp.detach()).reshape(-1)), Ov, Cv, _p(out["wv"]), _p(out["scv"]), _stream())
                 call("svnet_edgeblock_prepare_f32", _p(_f32c(W1p.detach())), _p(_f32c(beta1p.detach())), Os, Cs, Cv, _p(out["w_sign"]), _p(out["w_nz"]),
-                     _p(out["beta_perm"]), _p(out["w_dense"]), _stream())
-                call("svnet_edgeblock_wbt_bf16", _p(out["w_sign"]), _p(out["w_nz"]), Os, _p(out["wbt"]), _stream())
+                     _p(out["beta_perm"]), _stream())
+                call("svnet_edgeblock_wbt_bf16", _p(out["w_sign"]), _p(out["w_nz"]), Os, Cs, Cv, _p(out["wbt"]), _p(out["w_dense"]), _stream())
             rebuild()
             return out, rebuild
         packed = PLANES.get("edge", (W1, beta1, W2, sc2, Wz, scz), build)

@@ -39,11 +39,10 @@ __device__ __forceinline__ int fused_feature(int w, int b, int Cs, int Cv) {
     return b < 2 * Cv ? 2 * Cs + b * 3 + (w - 2) : -1;
 }
 
-constexpr int DENSE_WAVES = 8;     // waves of the packing kernel that look for exact zeros in W1 (SVNET_EDGE_DENSE_WORDS flags)
 // one wave per (output channel, word): lane b loads the weight of bit b, two ballots make the plane words
 __global__ __launch_bounds__(256) void edgeblock_prepare_kernel(const float* __restrict__ W, const float* __restrict__ beta, int Os, int Cs,
                                                                 int Cv, uint64_t* __restrict__ w_sign, uint64_t* __restrict__ w_nz,
-                                                                float* __restrict__ beta_perm, uint32_t* __restrict__ w_dense) {
+                                                                float* __restrict__ beta_perm) {
     const int K1 = 2 * Cs + 6 * Cv;
     const int lane = threadIdx.x & 63;
     const int item = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);      // (o, w) pairs, then the NW beta words
@@ -57,24 +56,6 @@ __global__ __launch_bounds__(256) void edgeblock_prepare_kernel(const float* __r
         const int w = item - Os * NW;
         const int f = fused_feature(w, lane, Cs, Cv);
         beta_perm[w * 64 + lane] = f >= 0 ? beta[f] : 0.f;
-    } else if (item < Os * NW + NW + DENSE_WAVES && w_dense) {
-        // DENSE_WAVES more waves: is every weight of the layer non-zero?  (sign(0) = 0 makes the weights ternary in principle -
-        // sv_layers.py:44-45 - but a trained or freshly initialised layer holds no exact zero: the forward kernels then skip the non-zero
-        // plane of the weights.)  Wave q scans its share of W, eight loads in flight per lane, and leaves its verdict in w_dense[q]
-        // (one wave walking all 32 K weights one load at a time added 0.1 ms to every re-pack of a training step).
-        const int q = item - (Os * NW + NW);
-        const int64_t total = (int64_t)Os * K1, per = (total + DENSE_WAVES - 1) / DENSE_WAVES;
-        const int64_t e0 = q * per, e1 = min(total, e0 + per);
-        bool any_zero = false;
-        for (int64_t e = e0 + lane; e < e1; e += 64 * 8) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = W[min(e + 64 * u, e1 - 1)];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) any_zero |= (v[u] == 0.f);
-        }
-        const uint64_t z = __ballot(any_zero);
-        if (lane == 0) w_dense[q] = z == 0ull ? 1u : 0u;
     }
 }
 
@@ -107,12 +88,8 @@ __device__ __forceinline__ void tacc(uint32_t xs, uint32_t xz, uint32_t ws, uint
 __device__ __forceinline__ void tacc_dense(uint64_t xs, uint64_t xz, uint64_t ws, int& pd) { pd += __popcll(xz & (xs ^ ws)); }
 __device__ __forceinline__ void tacc_dense(uint32_t xs, uint32_t xz, uint32_t ws, int& pd) { pd += __popc(xz & (xs ^ ws)); }
 
-__device__ __forceinline__ bool edge_weights_dense(const uint32_t* __restrict__ w_dense) {      // (wave-uniform: scalar loads)
-    if (!w_dense) return false;
-    uint32_t all = 1u;
-#pragma unroll
-    for (int q = 0; q < DENSE_WAVES; ++q) all &= w_dense[q];
-    return all == 1u;
+__device__ __forceinline__ bool edge_weights_dense(const uint32_t* __restrict__ w_dense) {      // (wave-uniform: a scalar load)
+    return w_dense && *w_dense == 1u;
 }
 
 // NARROW: every word has at most 32 columns in use (Cs <= 32 and 2 Cv <= 32): the popcount products run on the low halves only
@@ -757,11 +734,11 @@ __global__ __launch_bounds__(256) void edgeblock_apply_kernel(const int32_t* __r
 }  // namespace
 
 extern "C" int svnet_edgeblock_prepare_f32(const float* W, const float* beta, int64_t Os, int64_t Cs, int64_t Cv, uint64_t* w_sign,
-                                           uint64_t* w_nz, float* beta_perm, uint32_t* w_dense, void* stream) {
+                                           uint64_t* w_nz, float* beta_perm, void* stream) {
     SVNET_REQUIRE(W && beta && w_sign && w_nz && beta_perm, SVNET_E_ARG, "svnet_edgeblock_prepare_f32: null pointer");
     SVNET_REQUIRE(Cs > 0 && Cs <= 64 && Cv > 0 && 2 * Cv <= 64 && Os > 0, SVNET_E_UNSUPPORTED, "svnet_edgeblock_prepare_f32: needs Cs <= 64, 2*Cv <= 64");
-    hipLaunchKernelGGL(edgeblock_prepare_kernel, dim3((unsigned)svnet_cdiv((Os * NW + NW + DENSE_WAVES) * 64, 256)), dim3(256), 0, (hipStream_t)stream, W,
-                       beta, (int)Os, (int)Cs, (int)Cv, w_sign, w_nz, beta_perm, w_dense);
+    hipLaunchKernelGGL(edgeblock_prepare_kernel, dim3((unsigned)svnet_cdiv((Os * NW + NW) * 64, 256)), dim3(256), 0, (hipStream_t)stream, W,
+                       beta, (int)Os, (int)Cs, (int)Cv, w_sign, w_nz, beta_perm);
     SVNET_CHECK_LAUNCH("edgeblock_prepare_kernel");
     return SVNET_OK;
 }

@@ -159,8 +159,21 @@ __device__ __forceinline__ float wave_sum_last(float v) {
 // lane = h*32 + r holding column ct*32 + r, outputs o = ks*16 + 8h .. +7 (zero past Os).  A wave's fragment load is then 1 KiB
 // contiguous (8 cache lines); with the plain [column][o] table every lane pair sat on its own line - 32 lines per load instruction,
 // 24 such loads per wave and tile at Os = 128 - and the L1 tag pipe, not the matrix pipe, set the pace of phase B.
-__global__ void edgeblock_wbt_kernel(const uint64_t* __restrict__ w_sign, const uint64_t* __restrict__ w_nz, int Os,
-                                     uint16_t* __restrict__ wbt) {
+__global__ void edgeblock_wbt_kernel(const uint64_t* __restrict__ w_sign, const uint64_t* __restrict__ w_nz, int Os, int Cs, int Cv,
+                                     uint16_t* __restrict__ wbt, uint32_t* __restrict__ w_dense) {
+    // (optional) is every weight of the layer non-zero?  sign(0) = 0 makes the weights ternary in principle (sv_layers.py:44-45), but a
+    // trained or freshly initialised layer holds no exact zero: the forward kernels then skip the weights' non-zero plane.  The planes are
+    // complete here (the packing kernel ran before this one on the stream): the first wave checks the Os x 5 words against the columns in use.
+    if (w_dense && blockIdx.x == 0 && threadIdx.x < 64) {
+        bool ok = true;
+        for (int i = threadIdx.x; i < Os * NW; i += 64) {
+            const int w = i % NW, nb = w < 2 ? Cs : 2 * Cv;
+            const uint64_t used = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
+            ok = ok && ((w_nz[i] & used) == used);
+        }
+        const uint64_t bad = __ballot(!ok);
+        if (threadIdx.x == 0) *w_dense = bad == 0ull ? 1u : 0u;
+    }
     const int nks = (Os + 15) >> 4;
     const int total = (NCOL / 32) * nks * 512;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
@@ -1069,10 +1082,12 @@ __global__ __launch_bounds__(256, 4) void edgeblock_bwd_kernel(svnet_edgeblock_b
 
 }  // namespace
 
-extern "C" int svnet_edgeblock_wbt_bf16(const uint64_t* w_sign, const uint64_t* w_nz, int64_t Os, uint16_t* wbt, void* stream) {
+extern "C" int svnet_edgeblock_wbt_bf16(const uint64_t* w_sign, const uint64_t* w_nz, int64_t Os, int64_t Cs, int64_t Cv, uint16_t* wbt,
+                                        uint32_t* w_dense, void* stream) {
     SVNET_REQUIRE(w_sign && w_nz && wbt && Os > 0 && Os % 8 == 0, SVNET_E_ARG, "svnet_edgeblock_wbt_bf16: bad arguments (Os must be a multiple of 8)");
+    SVNET_REQUIRE(!w_dense || (Cs > 0 && Cs <= 64 && Cv > 0 && 2 * Cv <= 64), SVNET_E_ARG, "svnet_edgeblock_wbt_bf16: w_dense needs the layer's Cs <= 64, 2 Cv <= 64");
     hipLaunchKernelGGL(edgeblock_wbt_kernel, dim3((unsigned)svnet_cdiv(NCOL * ((Os + 15) / 16 * 16), 256)), dim3(256), 0, (hipStream_t)stream, w_sign, w_nz,
-                       (int)Os, wbt);
+                       (int)Os, (int)Cs, (int)Cv, wbt, w_dense);
     SVNET_CHECK_LAUNCH("edgeblock_wbt_kernel");
     return SVNET_OK;
 }
