@@ -47,7 +47,7 @@ int svnet_slices_sum_f64(double* buf, int64_t L, void* stream);
  * changes its required length (200: sliced accumulators, SVNET_SLICED_LEN; 400: this header; 401: the totals of a sliced accumulator are
  * written by its consumer, svnet_slices_sum_*; 402: GX of svnet_v2s_bwd_*, gw of svnet_xyzblock_bwd_f32 and col_sum of svnet_gemm_f32 are sliced accumulators; 403: svnet_binweight_grad_f32 takes sliced inputs).  svnet_version() returns the value the
  * library was BUILT with: a caller compiled against another header must refuse to run (svnet_amd/_lib.py does).                   */
-#define SVNET_ABI_VERSION 413
+#define SVNET_ABI_VERSION 414
 int svnet_version(void);
 const char* svnet_last_error(void);
 
@@ -500,13 +500,19 @@ int svnet_vtail_fwd_f32(const float* v, const double* sums, float eps, float mom
                         int workspace_zeroed /* != 0: the first B*3C*8 bytes (the arg-max keys) are zero already */, void* stream);
 /* Its backward up to VectorBN's batch sums, from the POOLED gradients (gmax / gmean: rows of stride g_ld): the gradient of the scalars,
  * (point == argmax ? gmax : 0) + gmean / N, is formed on the fly, Vector2Scalar's backward runs in registers.  Outputs: g5 [B*N, 3, C] =
- * dL/d(VectorBN's output), to be handed to svnet_vbn_bwd_apply_f32 as its `g` together with `red`; red = SLICED accumulator of 2C floats
+ * dL/d(VectorBN's output) (may be NULL: see svnet_vtail_bwd_apply_f32), to be handed to svnet_vbn_bwd_apply_f32 as its `g` together with `red`; red = SLICED accumulator of 2C floats
  * (SVNET_SLICED_LEN(2C), zero-filled; the apply pass adds the slices up and leaves [dbeta | dgamma]); dgate [B, C] (zero-filled, += ; may
  * be NULL when gate is); GX = sliced accumulator of 3C floats: dL/d(w_eff) as [3][C] (svnet_binweight_grad_f32 with gx_sliced).        */
 int svnet_vtail_bwd_f32(const float* v, const float* mean, const float* invstd, const float* gamma, const float* beta,
                         const float* gate, const float* w_eff, const float* gmax, const float* gmean, int64_t g_ld,
                         const int32_t* argmax, int64_t B, int64_t N, int64_t C, float* red, float* dgate, float* GX, float* g5,
                         void* stream);
+/* The rest of that backward WITHOUT the stored g5 (pass NULL for it above): the same per-point recomputation of dL/d(VectorBN's output), then
+ * VectorBN's apply pass on it (svnet_vbn_bwd_apply_f32's formulas) with the totals of `red`'s slices - dv [B*N, 3, C] = dL/dv, and
+ * [dbeta | dgamma] left in the first 2C elements of red.  One read of v and one write instead of two reads, a write and a read.          */
+int svnet_vtail_bwd_apply_f32(const float* v, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                              const float* gate, const float* w_eff, const float* gmax, const float* gmean, int64_t g_ld,
+                              const int32_t* argmax, int64_t B, int64_t N, int64_t C, float* red, int train_stats, float* dv, void* stream);
 /* dx[o,r,i] = add[(o*R + r)*add_ld + i] + gmean[o,i] / R: the backward of a mean over r (sv_layers.py:179: the gate's pooled input) added to
  * another gradient of the same tensor that arrives as rows of stride add_ld (the s columns of the gradient of cat[s, Vector2Scalar(v)],
  * sv_layers.py:187-188) - one pass instead of a broadcast pass and a strided elementwise add.                                       */

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVNET_DIAG_LIB") or os.path.join(_HERE, "libsvnet_hip.so")    # (SVNET_DIAG_LIB: an ablation build, tools/ only)
 _lib = None
-ABI_VERSION = 413       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
+ABI_VERSION = 414       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
 
 c_p = ctypes.c_void_p
 c_i64 = ctypes.c_int64
@@ -201,6 +201,7 @@ SIGNATURES = {
     "svnet_vtail_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
     "svnet_vtail_fwd_f32": (c_int, [c_p, c_p, c_f, c_f] + [c_p] * 9 + [c_i64] * 3 + [c_p, c_p, c_i64, c_p, c_p, c_sz, c_int, c_p]),
     "svnet_vtail_bwd_f32": (c_int, [c_p] * 9 + [c_i64, c_p] + [c_i64] * 3 + [c_p] * 5),
+    "svnet_vtail_bwd_apply_f32": (c_int, [c_p] * 9 + [c_i64, c_p] + [c_i64] * 3 + [c_p, c_int, c_p, c_p]),
     "svnet_act_fwd_f32": (c_int, [c_p, c_i64, c_int, c_p, c_p]),
     "svnet_act_bwd_f32": (c_int, [c_p, c_p, c_i64, c_int, c_p, c_p]),
     "svnet_vlinear_stats_f32": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_p, c_p]),

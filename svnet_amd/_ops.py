@@ -1487,11 +1487,16 @@ class GlobalMaxMeanPoolBNV(torch.autograd.Function):
             #  which autograd runs where its forward ran - so the allocator may hand their blocks on as soon as they are freed; allocated on the
             #  main stream, dv's block went back to the MAIN stream's pool while linear2's products were still reading it)
             dv = torch.empty((P, 3, C), dtype=F, device=dev)
-            g5 = torch.empty((P, 3, C), dtype=F, device=dev)
+            recompute = bool(config.FUSE_VTAIL_APPLY)
+            g5 = None if recompute else torch.empty((P, 3, C), dtype=F, device=dev)
             call("svnet_vtail_bwd_f32", _p(v3), _p(mean2), _p(invstd2), _p(g2), _p(b2), _p(gate2), _p(w_eff), _p(g[:, Ca:]), _p(g[:, Ct + Ca:]),
                  2 * Ct, _p(arg_b), B, N, C, _p(red2), _p(dgate) if gate2 is not None else None, _p(gxb), _p(g5), _stream())
-            call("svnet_vbn_bwd_apply_f32", _p(g5), _p(v3), _p(mean2), _p(invstd2), _p(g2), _p(b2), _p(gate2), _p(red2), N, P, C,
-                 int(training), _p(dv), _stream())
+            if recompute:   # the apply pass recomputes dL/d(VectorBN's output) from the product instead of reading a stored copy (134 MB less)
+                call("svnet_vtail_bwd_apply_f32", _p(v3), _p(mean2), _p(invstd2), _p(g2), _p(b2), _p(gate2), _p(w_eff), _p(g[:, Ca:]),
+                     _p(g[:, Ct + Ca:]), 2 * Ct, _p(arg_b), B, N, C, _p(red2), int(training), _p(dv), _stream())
+            else:
+                call("svnet_vbn_bwd_apply_f32", _p(g5), _p(v3), _p(mean2), _p(invstd2), _p(g2), _p(b2), _p(gate2), _p(red2), N, P, C,
+                     int(training), _p(dv), _stream())
             if sczf is not None:
                 dWz, dscz = _binweight_grad(gxb, Wzc, sczf, 3, C, training, gx_sliced=True)
                 dscz = dscz.view(scshape)

@@ -32,6 +32,8 @@ FUSE_BN_POOL = True
 # ... and conv5's VectorBN + gate, svfuse's Vector2Scalar and the pooling of its half as ONE pass over linear2's product each way
 # (csrc/vtail.hip, _ops.GlobalMaxMeanPoolBNV): VectorBN's output, the [B,N,510] scalars and their gradient are never written.
 FUSE_VTAIL = True
+# ... and its backward's second pass recomputes dL/d(VectorBN's output) per point instead of reading the copy the first pass would store
+FUSE_VTAIL_APPLY = True
 
 # SVBlock on rows: cat[s, Vector2Scalar(v)] written in place by the Vector2Scalar kernel (no intermediate, no cat pass).
 FUSE_V2S_CAT = True

@@ -136,10 +136,12 @@ __device__ __forceinline__ void vt_load_row(float (&a)[3][CPL], const float* __r
 // (one division per channel: v * (BN(n) / n * gate) - vbn_fwd_kernel divides every component, v / n * BN(n) * gate: the same value to an ulp)
 template <int CPL>
 __device__ __forceinline__ void vt_point(const float (&a)[3][CPL], const VtChan<CPL>& ch, float (&x)[3][CPL], float (&n)[CPL], float (&rr)[CPL],
-                                         float (&z)[3][J], int lane) {
+                                         float (&z)[3][J], int lane, float* nv_out = nullptr) {
 #pragma unroll
     for (int t = 0; t < CPL; ++t) {
-        n[t] = sqrtf(a[0][t] * a[0][t] + a[1][t] * a[1][t] + a[2][t] * a[2][t]) + VT_VEPS;
+        const float nv = sqrtf(a[0][t] * a[0][t] + a[1][t] * a[1][t] + a[2][t] * a[2][t]);
+        if (nv_out) nv_out[t] = nv;
+        n[t] = nv + VT_VEPS;
         rr[t] = (n[t] - ch.mu[t]) * ch.is[t] * ch.ga[t] + ch.be[t];
         const float q = rr[t] / n[t] * ch.gt[t];        // (no branch around the division: a dead channel reads channel 0, n > 0, gate 0)
 #pragma unroll
@@ -269,15 +271,17 @@ __global__ __launch_bounds__(256) void vtail_finish_kernel(const unsigned long l
     }
 }
 
-// ---- backward, first pass: everything up to VectorBN's batch sums; writes g5 = dL/dv5 for the apply pass (vbn_bwd_apply_kernel)
-template <int CPL>
+// ---- backward.  APPLY = false, first pass: everything up to VectorBN's batch sums (+ optionally g5 = dL/dv5 for vbn_bwd_apply_kernel).
+// APPLY = true, second pass: the SAME per-point recomputation of dL/dv5 (one read of the product instead of reading it and a stored g5),
+// then VectorBN's apply pass on it (vbn_bwd_apply_kernel's expressions) with the totals of the first pass's sums -> dv.
+template <int CPL, bool APPLY>
 __global__ __launch_bounds__(256) void vtail_bwd_kernel(const float* __restrict__ v, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ gate, const float* __restrict__ w,
                                                         const float* __restrict__ gmax, const float* __restrict__ gmean, int64_t g_ld,
                                                         const int32_t* __restrict__ argmax, int N, int C, int rows_per_chunk,
                                                         float* __restrict__ red, float* __restrict__ dgate, float* __restrict__ GX,
-                                                        float* __restrict__ g5) {
+                                                        float* __restrict__ g5, int train_stats, float* __restrict__ dv) {
     constexpr int NO = J * CPL;
     __shared__ double lacc[4][2 * CPL * 64];
     __shared__ float lgw[4][(NO + CPL) * 64];            // [wave][gxw (J*CPL) | gsum (CPL)][lane]
@@ -303,17 +307,34 @@ __global__ __launch_bounds__(256) void vtail_bwd_kernel(const float* __restrict_
         }
     float gxw[J][CPL], gsum[CPL];
     double acc0[CPL], acc1[CPL];
+    float r0c[CPL], r1c[CPL];                       // (APPLY) the totals of the first pass's sliced sums: sum dr, sum dr * nhat per channel
+    const float invM = 1.f / ((float)gridDim.y * (float)N);
 #pragma unroll
     for (int t = 0; t < CPL; ++t) {
-        gsum[t] = 0.f; acc0[t] = 0.0; acc1[t] = 0.0;
+        gsum[t] = 0.f; acc0[t] = 0.0; acc1[t] = 0.0; r0c[t] = 0.f; r1c[t] = 0.f;
 #pragma unroll
         for (int j = 0; j < J; ++j) gxw[j][t] = 0.f;
+        if (APPLY) {
+            const int c = lane + 64 * t, cc = c < C ? c : 0;
+            r0c[t] = svnet_slices_total(red, 2 * C, cc);
+            r1c[t] = svnet_slices_total(red, 2 * C, C + cc);
+        }
+    }
+    if (APPLY) {
+        // (every workgroup has read the slices before anyone overwrites the totals' slots [0, 2C): they are separate addresses)
+        if (blockIdx.x == 0 && blockIdx.y == 0 && wave == 0) {
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) {
+                const int c = lane + 64 * t;
+                if (c < C) { red[c] = r0c[t]; red[C + c] = r1c[t]; }
+            }
+        }
     }
     // one point (see the forward kernel: no branch in the body; `live` false = a clamped request past the chunk's end, whose pooled
     // gradient is taken as 0 - every sum it feeds then receives 0 - and whose row is not stored)
     auto point = [&](const float (&a)[3][CPL], int r, bool live) {
-        float x[3][CPL], n[CPL], rr[CPL], z[3][J];
-        vt_point<CPL>(a, ch, x, n, rr, z, lane);
+        float x[3][CPL], n[CPL], rr[CPL], z[3][J], nvv[CPL];
+        vt_point<CPL>(a, ch, x, n, rr, z, lane, nvv);
         // pooled gradient of this point's s_v, Vector2Scalar's backward (v2s_bwd_kernel's expressions)
         float d[CPL][J], dz[3][J];
 #pragma unroll
@@ -343,21 +364,37 @@ __global__ __launch_bounds__(256) void vtail_bwd_kernel(const float* __restrict_
                 for (int j = 0; j < J; ++j) sg += d[t][j] * z[i][j] + dz[i][j] * ch.w[j][t];
                 g[i] = sg;
             }
-#pragma unroll
-            for (int j = 0; j < J; ++j) gxw[j][t] += dz[0][j] * x[0][t] + dz[1][j] * x[1][t] + dz[2][j] * x[2][t];
-            if (ch.ok[t] && live) {                      // (exec-masked stores, no branch)
-                const int c = lane + 64 * t;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) g5[(m * 3 + i) * C + c] = g[i];
-            }
-            // VectorBN's reduce pass on g = dL/dv5 (vbn_bwd_reduce_kernel's expressions); a dead channel's g is 0
             const float nh = (n[t] - ch.mu[t]) * ch.is[t];
             const float gv = g[0] * a[0][t] + g[1] * a[1][t] + g[2] * a[2][t];
             const float rn = 1.f / n[t];
-            gsum[t] += gv * (rr[t] * rn);
-            const float dr = gv * ch.gt[t] * rn;
-            acc0[t] += (double)dr;
-            acc1[t] += (double)dr * (double)nh;
+            if (APPLY) {
+                // VectorBN's apply pass on g = dL/dv5 (vbn_bwd_apply_kernel's expressions: the gate multiplies g, dq = sum_i g_i v_i)
+                const float dq = gv * ch.gt[t];
+                float dr = dq * rn;
+                float dn = -dq * rr[t] * rn * rn;
+                if (train_stats) dr -= (r0c[t] + nh * r1c[t]) * invM;
+                dn += dr * ch.ga[t] * ch.is[t];
+                const float kk = nvv[t] > 0.f ? dn / nvv[t] : 0.f;
+                const float q = rr[t] * rn * ch.gt[t];
+                if (ch.ok[t] && live) {
+                    const int c = lane + 64 * t;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) dv[(m * 3 + i) * C + c] = g[i] * q + kk * a[i][t];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < J; ++j) gxw[j][t] += dz[0][j] * x[0][t] + dz[1][j] * x[1][t] + dz[2][j] * x[2][t];
+                if (g5 && ch.ok[t] && live) {            // (exec-masked stores, no branch; g5 NULL: the apply pass recomputes it)
+                    const int c = lane + 64 * t;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) g5[(m * 3 + i) * C + c] = g[i];
+                }
+                // VectorBN's reduce pass on g = dL/dv5 (vbn_bwd_reduce_kernel's expressions); a dead channel's g is 0
+                gsum[t] += gv * (rr[t] * rn);
+                const float dr = gv * ch.gt[t] * rn;
+                acc0[t] += (double)dr;
+                acc1[t] += (double)dr * (double)nh;
+            }
         }
     };
     float a[3][CPL], b[3][CPL];
@@ -371,6 +408,7 @@ __global__ __launch_bounds__(256) void vtail_bwd_kernel(const float* __restrict_
         __builtin_amdgcn_sched_barrier(0);
         point(b, r + 4, r + 4 < r1);
     }
+    if (APPLY) return;
     // workgroup sums in wave order, then ONE add per output and workgroup
 #pragma unroll
     for (int t = 0; t < CPL; ++t) {
@@ -459,7 +497,7 @@ extern "C" int svnet_vtail_bwd_f32(const float* v, const float* mean, const floa
                                    const float* gate, const float* w_eff, const float* gmax, const float* gmean, int64_t g_ld,
                                    const int32_t* argmax, int64_t B, int64_t N, int64_t C, float* red, float* dgate, float* GX, float* g5,
                                    void* stream) {
-    SVNET_REQUIRE(v && mean && invstd && gamma && beta && w_eff && gmax && gmean && argmax && red && GX && g5, SVNET_E_ARG,
+    SVNET_REQUIRE(v && mean && invstd && gamma && beta && w_eff && gmax && gmean && argmax && red && GX, SVNET_E_ARG,
                   "svnet_vtail_bwd_f32: null pointer");
     SVNET_REQUIRE(B > 0 && B <= 65535 && N > 0 && N < (1 << 30) && C > 0 && g_ld >= 3 * C && (!gate || dgate), SVNET_E_ARG,
                   "svnet_vtail_bwd_f32: bad sizes");
@@ -468,12 +506,34 @@ extern "C" int svnet_vtail_bwd_f32(const float* v, const float* mean, const floa
     int64_t chunks, rpc;
     vtail_chunks(B, N, chunks, rpc);
     const dim3 grid((unsigned)chunks, (unsigned)B);
-#define SVNET_VT_BWD(CPL_) hipLaunchKernelGGL((vtail_bwd_kernel<CPL_>), grid, dim3(256), 0, st, v, mean, invstd, gamma, beta, gate, w_eff, gmax, gmean, g_ld, \
-                                              argmax, (int)N, (int)C, (int)rpc, red, dgate, GX, g5)
+#define SVNET_VT_BWD(CPL_) hipLaunchKernelGGL((vtail_bwd_kernel<CPL_, false>), grid, dim3(256), 0, st, v, mean, invstd, gamma, beta, gate, w_eff, gmax, gmean, g_ld, \
+                                              argmax, (int)N, (int)C, (int)rpc, red, dgate, GX, g5, 0, (float*)nullptr)
     if (C <= 64) SVNET_VT_BWD(1);
     else if (C <= 128) SVNET_VT_BWD(2);
     else SVNET_VT_BWD(3);
 #undef SVNET_VT_BWD
     SVNET_CHECK_LAUNCH("vtail_bwd_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_vtail_bwd_apply_f32(const float* v, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                         const float* gate, const float* w_eff, const float* gmax, const float* gmean, int64_t g_ld,
+                                         const int32_t* argmax, int64_t B, int64_t N, int64_t C, float* red, int train_stats, float* dv,
+                                         void* stream) {
+    SVNET_REQUIRE(v && mean && invstd && gamma && beta && w_eff && gmax && gmean && argmax && red && dv, SVNET_E_ARG,
+                  "svnet_vtail_bwd_apply_f32: null pointer");
+    SVNET_REQUIRE(B > 0 && B <= 65535 && N > 0 && N < (1 << 30) && C > 0 && g_ld >= 3 * C, SVNET_E_ARG, "svnet_vtail_bwd_apply_f32: bad sizes");
+    SVNET_REQUIRE(C <= 192, SVNET_E_UNSUPPORTED, "svnet_vtail_bwd_apply_f32: C=%lld > 192 vector channels", (long long)C);
+    hipStream_t st = (hipStream_t)stream;
+    int64_t chunks, rpc;
+    vtail_chunks(B, N, chunks, rpc);
+    const dim3 grid((unsigned)chunks, (unsigned)B);
+#define SVNET_VT_APPLY(CPL_) hipLaunchKernelGGL((vtail_bwd_kernel<CPL_, true>), grid, dim3(256), 0, st, v, mean, invstd, gamma, beta, gate, w_eff, gmax, gmean, \
+                                                g_ld, argmax, (int)N, (int)C, (int)rpc, red, (float*)nullptr, (float*)nullptr, (float*)nullptr, train_stats, dv)
+    if (C <= 64) SVNET_VT_APPLY(1);
+    else if (C <= 128) SVNET_VT_APPLY(2);
+    else SVNET_VT_APPLY(3);
+#undef SVNET_VT_APPLY
+    SVNET_CHECK_LAUNCH("vtail_bwd_kernel<apply>");
     return SVNET_OK;
 }

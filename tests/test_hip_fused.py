@@ -335,16 +335,19 @@ def test_bn_pool_fused_equals_bn_act_then_pool(training, hip_device):
         assert float((a_ - b_).abs().max()) <= 1e-5 * max(float(b_.abs().max()), 1e-6), n
 
 
+@pytest.mark.parametrize("recompute", [True, False], ids=["apply_recomputes", "apply_reads_g5"])
 @pytest.mark.parametrize("training", [True, False], ids=["train", "eval"])
 @pytest.mark.parametrize("cfg", [(3, 300, 70, 45, True), (2, 1024, 64, 170, True), (4, 257, 96, 100, False), (2, 256, 32, 64, True)],
                          ids=["c45", "c170", "c100_fp", "c64"])
-def test_vector_tail_fused_equals_vectorbn_v2s_then_pool(cfg, training, hip_device):
+def test_vector_tail_fused_equals_vectorbn_v2s_then_pool(cfg, training, recompute, hip_device, monkeypatch):
     """_ops.GlobalMaxMeanPoolBNV (csrc/vtail.hip: conv5's VectorBN + gate, svfuse's Vector2Scalar and the [max | mean] pooling of its
     half in one pass over linear2's product each way; sv_layers.py:86-102,111-129,193-194,206-220, sv_dgcnn_cls.py:68-74) against the
     layer-wise chain VBN -> V2S -> GlobalMaxMeanPoolBN on the same inputs: the scalar half bit-identical, the vector half's pooled
     values / statistics / every gradient to 2e-5 of the tensor's largest element (other contraction and summation orders), arg-max equal
-    but for near-ties, first index on exact ties."""
-    from svnet_amd import _ops
+    but for near-ties, first index on exact ties.  Both forms of the backward's second pass: recomputing dL/d(VectorBN's output) per
+    point (svnet_vtail_bwd_apply_f32, the default) and reading the copy the first pass stores (svnet_vbn_bwd_apply_f32)."""
+    from svnet_amd import _ops, config
+    monkeypatch.setattr(config, "FUSE_VTAIL_APPLY", recompute)
     B, N, Ca, C, binary = cfg
     g = torch.Generator().manual_seed(33 + C)
     y = torch.randn(B, N, Ca, generator=g) * 2.0
