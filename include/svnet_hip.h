@@ -47,7 +47,7 @@ int svnet_slices_sum_f64(double* buf, int64_t L, void* stream);
  * changes its required length (200: sliced accumulators, SVNET_SLICED_LEN; 400: this header; 401: the totals of a sliced accumulator are
  * written by its consumer, svnet_slices_sum_*; 402: GX of svnet_v2s_bwd_*, gw of svnet_xyzblock_bwd_f32 and col_sum of svnet_gemm_f32 are sliced accumulators; 403: svnet_binweight_grad_f32 takes sliced inputs).  svnet_version() returns the value the
  * library was BUILT with: a caller compiled against another header must refuse to run (svnet_amd/_lib.py does).                   */
-#define SVNET_ABI_VERSION 414
+#define SVNET_ABI_VERSION 415
 int svnet_version(void);
 const char* svnet_last_error(void);
 
@@ -80,6 +80,26 @@ int svnet_knn_f32(const float* x, int64_t B, int64_t N, int64_t C, int64_t sb, i
  * Workspace: svnet_knn_workspace_bytes(B, N, Cs + Cv3).                                               */
 int svnet_knn_sv_f32(const float* s, int64_t Cs, const float* v, int64_t Cv3, int64_t B, int64_t N, int k, int64_t* idx_out,
                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* The candidate table of a k-NN call prepared by the PRODUCER of the features (the apply pass of the previous fused level): the k-NN is
+ * on the forward's critical path and its first kernel only re-reads, squares and transposes what that pass has just written
+ * (sv_dgcnn_cls.py:55-65: svpool(conv_l(..)) -> get_graph_feature_sv -> knn).  svnet_knn_table_fusable: 1 when the table of (B, N, C)
+ * is the channel-major one the producers write and N % 32 == 0.  svnet_edgeblock_apply_knn_f32 / svnet_xyzblock_apply_knn_f32: the apply
+ * pass of svnet_edgeblock_apply_f32 / svnet_xyzblock_apply_f32 (same arguments, bit-identical s_out / v_out / slices) that also fills
+ * knn_workspace (svnet_knn_workspace_bytes(P / N, N, Os + 3 Ov)) with the table and the ||x||^2 of the rows cat[s, v.view(3 Ov)]
+ * (sv_util.py:100; ATen's contiguous-row recipe, bit for bit what svnet_knn_sv_f32 computes).  svnet_knn_from_table_f32: the k-NN
+ * proper on such a workspace - idx_out as svnet_knn_f32.                                                                            */
+int svnet_knn_table_fusable(int64_t B, int64_t N, int64_t C);
+int svnet_knn_from_table_f32(const void* workspace, size_t workspace_bytes, int64_t B, int64_t N, int64_t C, int k, int64_t* idx_out,
+                             void* stream);
+int svnet_edgeblock_apply_knn_f32(const int32_t* n_max, const int32_t* n_min, const float* mv, const float* mvn, const float* coef,
+                                  const float* gate, int64_t P, int64_t N, int64_t Os, int64_t Ov, float slope, float* s_out, float* v_out,
+                                  float* s_cat, int64_t s_ld, float* v_cat, int64_t v_ld, void* knn_workspace, size_t knn_workspace_bytes,
+                                  void* stream);
+int svnet_xyzblock_apply_knn_f32(const float* y_max, const float* y_min, const float* mv, const float* mvn, const float* coef,
+                                 const float* gate, int64_t P, int64_t N, int64_t Os, int64_t Ov, float slope, float* s_out, float* v_out,
+                                 float* s_cat, int64_t s_ld, float* v_cat, int64_t v_ld, void* knn_workspace, size_t knn_workspace_bytes,
+                                 void* stream);
 
 /* ------------------------------------------------------------------ edge features from xyz
  * (sv_util.py:28-62 get_graph_feature, :64-88 get_graph_feature_cross)

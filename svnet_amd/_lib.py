@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVNET_DIAG_LIB") or os.path.join(_HERE, "libsvnet_hip.so")    # (SVNET_DIAG_LIB: an ablation build, tools/ only)
 _lib = None
-ABI_VERSION = 414       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
+ABI_VERSION = 415       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
 
 c_p = ctypes.c_void_p
 c_i64 = ctypes.c_int64
@@ -143,6 +143,8 @@ SIGNATURES = {
     "svnet_knn_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
     "svnet_knn_f32": (c_int, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p, c_p, c_sz, c_p]),
     "svnet_knn_sv_f32": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_int, c_p, c_p, c_sz, c_p]),
+    "svnet_knn_table_fusable": (c_int, [c_i64, c_i64, c_i64]),
+    "svnet_knn_from_table_f32": (c_int, [c_p, c_sz, c_i64, c_i64, c_i64, c_int, c_p, c_p]),
     "svnet_edge_xyz_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_int, c_p, c_p]),
     "svnet_edge_diffcat_fwd_f32": (c_int, [c_p, c_p, c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
     "svnet_edge_diffcat_bwd_f32": (c_int, [c_p, c_p, c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),
@@ -160,6 +162,7 @@ SIGNATURES = {
     "svnet_edgeblock_fwd_f32": (c_int, [ctypes.POINTER(EdgeBlockDesc), c_p]),
     "svnet_edgeblock_coeffs_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
     "svnet_edgeblock_apply_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p, c_i64, c_p, c_i64, c_p]),
+    "svnet_edgeblock_apply_knn_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p, c_i64, c_p, c_i64, c_p, c_sz, c_p]),
     "svnet_edgeblock_wbt_bf16": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "svnet_edgeblock_bwd_prelude_f32": (c_int, [c_p] * 9 + [c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_i64, c_p, c_p]),
     "svnet_edgeblock_bwd_coeffs_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
@@ -168,6 +171,7 @@ SIGNATURES = {
     "svnet_xyzblock_fwd_f32": (c_int, [ctypes.POINTER(XyzBlockDesc), c_p]),
     "svnet_xyzblock_coeffs_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
     "svnet_xyzblock_apply_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p, c_i64, c_p, c_i64, c_p]),
+    "svnet_xyzblock_apply_knn_f32": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p, c_i64, c_p, c_i64, c_p, c_sz, c_p]),
     "svnet_xyzblock_bwd_prelude_f32": (c_int, [c_p] * 8 + [c_i64, c_i64, c_i64, c_i64, c_f, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_i64, c_p, c_p]),
     "svnet_xyzblock_bwd_f32": (c_int, [ctypes.POINTER(XyzBlockBwdDesc), c_p]),
     "svnet_binweight_i8_bytes": (c_sz, [c_i64, c_i64]),

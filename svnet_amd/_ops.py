@@ -117,6 +117,40 @@ def knn(x, k):
     return idx
 
 
+class knn_table_ahead:
+    """`with knn_table_ahead():` around a fused level whose pooled (s, v) is read next by get_graph_feature_sv (sv_dgcnn_cls.py:55-65):
+    the level's apply pass then also writes the candidate table of that k-NN (svnet_*_apply_knn_f32: the k-NN is on the forward's
+    critical path and its first kernel only re-read, squared and transposed those rows), and knn_sv on exactly those tensors skips
+    its preparation.  Anything else - other tensors, a shape the fused producer does not take - runs the plain path."""
+    active = 0
+    table = None                            # (s.data_ptr(), v.data_ptr(), workspace, B, N, C) of the last prepared level
+
+    def __enter__(self):
+        knn_table_ahead.active += 1
+        return self
+
+    def __exit__(self, *exc):
+        knn_table_ahead.active -= 1
+        return False
+
+    @staticmethod
+    def workspace(B, N, Os, Ov, dev):
+        """The workspace the apply pass should fill, or None (context off, switch off, unsupported shape)."""
+        if not (knn_table_ahead.active and config.KNN_TABLE_AHEAD):
+            return None
+        L = _lib.lib()
+        if not L.svnet_knn_table_fusable(B, N, Os + 3 * Ov):
+            return None
+        return torch.empty(L.svnet_knn_workspace_bytes(B, N, Os + 3 * Ov), dtype=torch.uint8, device=dev)
+
+    @staticmethod
+    def take(s, v):
+        t, knn_table_ahead.table = knn_table_ahead.table, None
+        if t is None or t[0] != s.data_ptr() or t[1] != v.data_ptr() or t[3:] != (s.shape[0], s.shape[1], s.shape[2] + 3 * v.shape[-1]):
+            return None
+        return t[2]
+
+
 def knn_sv(s, v, k):
     """Feature-space graph of get_graph_feature_sv (sv_util.py:100-101): knn(cat[s, v.view(B,N,3Cv)].transpose(-1,-2), k) without
     the concatenated copy.  s [B,N,Cs], v [B,N,3,Cv] -> idx [B,N,k] int64."""
@@ -125,10 +159,14 @@ def knn_sv(s, v, k):
     _check_finite("knn (feature space)", s, v)
     B, N, Cs = s.shape
     Cv3 = 3 * v.shape[-1]
-    nbytes = _lib.lib().svnet_knn_workspace_bytes(B, N, Cs + Cv3)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=s.device)
     idx = torch.empty((B, N, k), dtype=torch.int64, device=s.device)
-    call("svnet_knn_sv_f32", _p(s), Cs, _p(v), Cv3, B, N, int(k), _p(idx), _p(ws), nbytes, _stream())
+    ws = knn_table_ahead.take(s, v)
+    if ws is not None:                       # the producer of (s, v) has prepared the table
+        call("svnet_knn_from_table_f32", _p(ws), ws.numel(), B, N, Cs + Cv3, int(k), _p(idx), _stream())
+    else:
+        nbytes = _lib.lib().svnet_knn_workspace_bytes(B, N, Cs + Cv3)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=s.device)
+        call("svnet_knn_sv_f32", _p(s), Cs, _p(v), Cv3, B, N, int(k), _p(idx), _p(ws), nbytes, _stream())
     if TAP is not None:
         TAP["knn"].append(idx)
     return idx
@@ -1857,8 +1895,14 @@ class EdgeBlock(torch.autograd.Function):
         s_out = torch.empty((B, N, Os), **f32)
         v_out = torch.empty((B, N, 3, Ov), **f32)
         slot = _SINK.slot(B, N, Os, Ov, dev) if _SINK is not None else None
-        call("svnet_edgeblock_apply_f32", _p(n_max), _p(n_min), _p(mv), _p(mvn), _p(coef), _p(gate), P, N, Os, Ov, 0.2, _p(s_out),
-             _p(v_out), *(slot if slot is not None else (None, 0, None, 0)), _stream())
+        kws = knn_table_ahead.workspace(B, N, Os, Ov, dev)
+        if kws is not None:
+            call("svnet_edgeblock_apply_knn_f32", _p(n_max), _p(n_min), _p(mv), _p(mvn), _p(coef), _p(gate), P, N, Os, Ov, 0.2, _p(s_out),
+                 _p(v_out), *(slot if slot is not None else (None, 0, None, 0)), _p(kws), kws.numel(), _stream())
+            knn_table_ahead.table = (s_out.data_ptr(), v_out.data_ptr(), kws, B, N, Os + 3 * Ov)
+        else:
+            call("svnet_edgeblock_apply_f32", _p(n_max), _p(n_min), _p(mv), _p(mvn), _p(coef), _p(gate), P, N, Os, Ov, 0.2, _p(s_out),
+                 _p(v_out), *(slot if slot is not None else (None, 0, None, 0)), _stream())
         s_view, v_view = _SINK.wrote(s_out, v_out) if slot is not None else (None, None)
         if TAP is not None:      # the pooled slot: BatchNorm + LeakyReLU is increasing (slope coef[o] >= 0: max_k n) or decreasing (min_k n)
             TAP["pools"].append(torch.where(coef[:Os].view(1, Os) >= 0, slot_max, slot_min))
@@ -2089,8 +2133,14 @@ class XyzBlock(torch.autograd.Function):
         s_out = torch.empty((B, N, Os), **f32)
         v_out = torch.empty((B, N, 3, Ov), **f32)
         slot = _SINK.slot(B, N, Os, Ov, dev) if _SINK is not None else None
-        call("svnet_xyzblock_apply_f32", _p(y_max), _p(y_min), _p(mv), _p(mvn), _p(coef), _p(gate), P, N, Os, Ov, 0.2, _p(s_out), _p(v_out),
-             *(slot if slot is not None else (None, 0, None, 0)), _stream())
+        kws = knn_table_ahead.workspace(B, N, Os, Ov, dev)
+        if kws is not None:
+            call("svnet_xyzblock_apply_knn_f32", _p(y_max), _p(y_min), _p(mv), _p(mvn), _p(coef), _p(gate), P, N, Os, Ov, 0.2, _p(s_out),
+                 _p(v_out), *(slot if slot is not None else (None, 0, None, 0)), _p(kws), kws.numel(), _stream())
+            knn_table_ahead.table = (s_out.data_ptr(), v_out.data_ptr(), kws, B, N, Os + 3 * Ov)
+        else:
+            call("svnet_xyzblock_apply_f32", _p(y_max), _p(y_min), _p(mv), _p(mvn), _p(coef), _p(gate), P, N, Os, Ov, 0.2, _p(s_out), _p(v_out),
+                 *(slot if slot is not None else (None, 0, None, 0)), _stream())
         s_view, v_view = _SINK.wrote(s_out, v_out) if slot is not None else (None, None)
         if TAP is not None:
             TAP["pools"].append(torch.where(coef[:Os].view(1, Os) >= 0, slot_max, slot_min))

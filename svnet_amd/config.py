@@ -85,3 +85,5 @@ GATE_MEAN_INSIDE = True
 # Fused forward edge kernels: when no weight of linear1 is exactly 0 (a device-side flag the packing kernel sets) the popcount products skip
 # the weights' non-zero plane: the edge's own non-zero count is one scalar per edge, a word costs xor + and + bcnt instead of five instructions
 EDGE_DENSE_WEIGHTS = True
+# A fused level followed by get_graph_feature_sv prepares that k-NN's candidate table in its apply pass (_ops.knn_table_ahead)
+KNN_TABLE_AHEAD = True

@@ -21,6 +21,7 @@
 
 #include "common.h"
 #include "gate_mlp.h"
+#include "apply_knn.h"
 
 namespace {
 
@@ -701,13 +702,33 @@ __global__ void edgeblock_coeffs_kernel(const long long* __restrict__ stat_n, co
 }
 
 // Pooled outputs: s_out = lrelu(A1 * (A1 >= 0 ? n_max : n_min) + B1); v_out = gate * (Av*mv + Bv*mvn).
+// (one functor for both apply kernels below: the same expressions, so the same contraction - their outputs are bit-identical,
+//  tests/test_hip_fused.py)
+struct EdgeApplyMath {
+    const int32_t* __restrict__ n_max; const int32_t* __restrict__ n_min;
+    const float* __restrict__ mv; const float* __restrict__ mvn;
+    const float* __restrict__ A1; const float* __restrict__ B1; const float* __restrict__ Av; const float* __restrict__ Bv;
+    const float* __restrict__ gate;
+    int Os, Ov;
+    float slope;
+    __device__ __forceinline__ float s(int64_t p, int o) const {
+        const float a = A1[o];
+        const float y = a * (float)(a >= 0.f ? n_max[p * Os + o] : n_min[p * Os + o]) + B1[o];
+        return y > 0.f ? y : y * slope;
+    }
+    __device__ __forceinline__ float v(int64_t p, int64_t b, int q, int c) const {
+        const int64_t e = p * 3 * Ov + q;
+        return gate[b * Ov + c] * (Av[c] * mv[e] + Bv[c] * mvn[e]);
+    }
+};
+
 __global__ __launch_bounds__(256) void edgeblock_apply_kernel(const int32_t* __restrict__ n_max, const int32_t* __restrict__ n_min,
                                                               const float* __restrict__ mv, const float* __restrict__ mvn,
                                                               const float* __restrict__ coef, const float* __restrict__ gate,
                                                               int64_t P, int64_t N, int Os, int Ov, float slope,
                                                               float* __restrict__ s_out, float* __restrict__ v_out, float* __restrict__ s_cat,
                                                               int64_t s_ld, float* __restrict__ v_cat, int64_t v_ld) {
-    const float* A1 = coef; const float* B1 = coef + Os; const float* Av = coef + 4 * Os; const float* Bv = Av + Ov;
+    const EdgeApplyMath m = {n_max, n_min, mv, mvn, coef, coef + Os, coef + 4 * Os, coef + 4 * Os + Ov, gate, Os, Ov, slope};
     // a wave per point row: lanes over the Os scalar channels, then over the 3*Ov vector entries - no per-element divisions (the flat
     // e -> (e % Os, q % Ov, q / 3Ov, p / N) form spent four 64-bit divisions on every output)
     const int lane = threadIdx.x & 63;
@@ -715,20 +736,30 @@ __global__ __launch_bounds__(256) void edgeblock_apply_kernel(const int32_t* __r
     for (int64_t p = wave0; p < P; p += nwaves) {
         const int64_t b = p / N;
         for (int o = lane; o < Os; o += 64) {
-            const float a = A1[o];
-            const float y = a * (float)(a >= 0.f ? n_max[p * Os + o] : n_min[p * Os + o]) + B1[o];
-            const float z = y > 0.f ? y : y * slope;
+            const float z = m.s(p, o);
             s_out[p * Os + o] = z;
             if (s_cat) s_cat[p * s_ld + o] = z;            // (the level's column slice of the pyramid's concatenation, written in place)
         }
         for (int q = lane; q < 3 * Ov; q += 64) {
             const int dd = q >= 2 * Ov ? 2 : (q >= Ov ? 1 : 0), c = q - dd * Ov;
-            const int64_t e = p * 3 * Ov + q;
-            const float z = gate[b * Ov + c] * (Av[c] * mv[e] + Bv[c] * mvn[e]);
-            v_out[e] = z;
+            const float z = m.v(p, b, q, c);
+            v_out[p * 3 * Ov + q] = z;
             if (v_cat) v_cat[(p * 3 + dd) * v_ld + c] = z;
         }
     }
+}
+
+// ... and the same pass preparing the k-NN table of its output (apply_knn.h)
+__global__ __launch_bounds__(256) void edgeblock_apply_knn_kernel(const int32_t* __restrict__ n_max, const int32_t* __restrict__ n_min,
+                                                                  const float* __restrict__ mv, const float* __restrict__ mvn,
+                                                                  const float* __restrict__ coef, const float* __restrict__ gate,
+                                                                  int64_t P, int64_t N, int Os, int Ov, float slope,
+                                                                  float* __restrict__ s_out, float* __restrict__ v_out,
+                                                                  float* __restrict__ s_cat, int64_t s_ld, float* __restrict__ v_cat,
+                                                                  int64_t v_ld, float* __restrict__ xT, float* __restrict__ xx, int64_t Cpad) {
+    extern __shared__ float apply_knn_rows[];
+    const EdgeApplyMath m = {n_max, n_min, mv, mvn, coef, coef + Os, coef + 4 * Os, coef + 4 * Os + Ov, gate, Os, Ov, slope};
+    apply_knn_tiles<APPLY_KNN_TP>(m, P, N, Os, Ov, s_out, v_out, s_cat, s_ld, v_cat, v_ld, xT, xx, Cpad, apply_knn_rows);
 }
 
 }  // namespace
@@ -817,5 +848,26 @@ extern "C" int svnet_edgeblock_apply_f32(const int32_t* n_max, const int32_t* n_
     hipLaunchKernelGGL(edgeblock_apply_kernel, dim3(svnet_grid(P * 64, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, n_max, n_min,
                        mv, mvn, coef, gate, P, N, (int)Os, (int)Ov, slope, s_out, v_out, s_cat, s_ld, v_cat, v_ld);
     SVNET_CHECK_LAUNCH("edgeblock_apply_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_edgeblock_apply_knn_f32(const int32_t* n_max, const int32_t* n_min, const float* mv, const float* mvn,
+                                             const float* coef, const float* gate, int64_t P, int64_t N, int64_t Os, int64_t Ov,
+                                             float slope, float* s_out, float* v_out, float* s_cat, int64_t s_ld, float* v_cat,
+                                             int64_t v_ld, void* knn_workspace, size_t knn_workspace_bytes, void* stream) {
+    SVNET_REQUIRE(n_max && n_min && mv && mvn && coef && gate && s_out && v_out && knn_workspace && P > 0 && N > 0 && P % N == 0, SVNET_E_ARG,
+                  "svnet_edgeblock_apply_knn_f32: bad arguments");
+    SVNET_REQUIRE((!s_cat || s_ld >= Os) && (!v_cat || v_ld >= Ov), SVNET_E_ARG, "svnet_edgeblock_apply_knn_f32: concatenation row shorter than the slice");
+    int64_t Cpad = 0;
+    SVNET_REQUIRE(apply_knn_supported(P, N, Os, Ov, &Cpad), SVNET_E_UNSUPPORTED,
+                  "svnet_edgeblock_apply_knn_f32: N=%lld, Os=%lld, Ov=%lld not supported (ask svnet_knn_table_fusable first)", (long long)N,
+                  (long long)Os, (long long)Ov);
+    SVNET_REQUIRE(knn_workspace_bytes >= svnet_knn_workspace_bytes(P / N, N, Os + 3 * Ov), SVNET_E_WORKSPACE,
+                  "svnet_edgeblock_apply_knn_f32: k-NN workspace too small");
+    float* xT = (float*)knn_workspace;
+    float* xx = xT + P * ((Os + 3 * Ov + 7) / 8 * 8);
+    hipLaunchKernelGGL(edgeblock_apply_knn_kernel, dim3((unsigned)(P / APPLY_KNN_TP)), dim3(256), apply_knn_lds_bytes(Os, Ov), (hipStream_t)stream,
+                       n_max, n_min, mv, mvn, coef, gate, P, N, (int)Os, (int)Ov, slope, s_out, v_out, s_cat, s_ld, v_cat, v_ld, xT, xx, Cpad);
+    SVNET_CHECK_LAUNCH("edgeblock_apply_knn_kernel");
     return SVNET_OK;
 }

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "knn_table.h"
 
 #ifndef SVNET_KNN_ABL
 #define SVNET_KNN_ABL 0
@@ -35,128 +36,6 @@
 
 
 namespace {
-
-struct Cascade {  // ATen multi_row_sum: 4 levels, level step 16
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int i = 0;
-    __device__ __forceinline__ void add(float v) {
-        a0 = __fadd_rn(a0, v);
-        ++i;
-        if ((i & 15) == 0) {
-            a1 = __fadd_rn(a1, a0);
-            a0 = 0.f;
-            if ((i & 0xF0) == 0) {
-                a2 = __fadd_rn(a2, a1);
-                a1 = 0.f;
-                if ((i & 0xF00) == 0) {
-                    a3 = __fadd_rn(a3, a2);
-                    a2 = 0.f;
-                }
-            }
-        }
-    }
-    __device__ __forceinline__ float total() const {
-        return __fadd_rn(__fadd_rn(__fadd_rn(a0, a1), a2), a3);
-    }
-};
-
-// The walk over one point's channels: ||x||^2 with ATen's exact recipe for the layout torch reduces (xx_mode), every value handed
-// to dst.put on the way (the transposition; a no-op for callers that transpose separately).
-template <class SrcT, class DstT>
-__device__ __forceinline__ float knn_xx_walk(const SrcT& src, const DstT& dst, int64_t C, int64_t N, int64_t n, int64_t sc, int xx_mode) {
-    float result;
-    if (xx_mode == 0) {
-        // outer-dim reduction: columns n < 32*floor(N/32) use one cascade, the rest ATen's row_sum (ilp 4)
-        if (n < (N / 32) * 32) {
-            Cascade cs;
-            for (int64_t c = 0; c < C; ++c) {
-                float v = src[c * sc];
-                dst.put(c, v);
-                cs.add(__fmul_rn(v, v));
-            }
-            result = cs.total();
-        } else {
-            Cascade part[4];
-            const int64_t ng = C / 4;
-            for (int64_t g = 0; g < ng; ++g) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = src[(4 * g + r) * sc];
-                    dst.put((4 * g + r), v);
-                    part[r].add(__fmul_rn(v, v));
-                }
-            }
-            float p0 = part[0].total(), p1 = part[1].total(), p2 = part[2].total(), p3 = part[3].total();
-            for (int64_t c = ng * 4; c < C; ++c) {
-                float v = src[c * sc];
-                dst.put(c, v);
-                p0 = __fadd_rn(p0, __fmul_rn(v, v));
-            }
-            result = __fadd_rn(__fadd_rn(__fadd_rn(p0, p1), p2), p3);
-        }
-    } else if (C < 8) {
-        // contiguous-dim reduction of a row shorter than one 8-lane vector: scalar row_sum (ilp 4)
-        float part[4] = {0.f, 0.f, 0.f, 0.f};
-        const int64_t ng = C / 4;
-        for (int64_t g = 0; g < ng; ++g) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = src[(4 * g + r) * sc];
-                dst.put((4 * g + r), v);
-                part[r] = __fadd_rn(part[r], __fmul_rn(v, v));
-            }
-        }
-        for (int64_t c = ng * 4; c < C; ++c) {
-            float v = src[c * sc];
-            dst.put(c, v);
-            part[0] = __fadd_rn(part[0], __fmul_rn(v, v));
-        }
-        result = __fadd_rn(__fadd_rn(__fadd_rn(part[0], part[1]), part[2]), part[3]);
-    } else {
-        // contiguous-dim reduction: 8-lane vectors, 4 interleaved vector accumulators (C <= 384 < 512,
-        // so the inner cascade never spills a level), leftover vectors into accumulator 0,
-        // lanes combined p0+p1+p2+p3, then scalar tail first, then the 8 lanes in order.
-        float p[4][8];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int l = 0; l < 8; ++l) p[r][l] = 0.f;
-        const int64_t nv = C / 8, ng = nv / 4;
-        for (int64_t g = 0; g < ng; ++g) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int l = 0; l < 8; ++l) {
-                    const int64_t c = (4 * g + r) * 8 + l;
-                    float v = src[c * sc];
-                    dst.put(c, v);
-                    p[r][l] = __fadd_rn(p[r][l], __fmul_rn(v, v));
-                }
-        }
-        for (int64_t g = ng * 4; g < nv; ++g) {
-#pragma unroll
-            for (int l = 0; l < 8; ++l) {
-                const int64_t c = g * 8 + l;
-                float v = src[c * sc];
-                dst.put(c, v);
-                p[0][l] = __fadd_rn(p[0][l], __fmul_rn(v, v));
-            }
-        }
-        float fin = 0.f;
-        for (int64_t c = nv * 8; c < C; ++c) {
-            float v = src[c * sc];
-            dst.put(c, v);
-            fin = __fadd_rn(fin, __fmul_rn(v, v));
-        }
-#pragma unroll
-        for (int l = 0; l < 8; ++l) {
-            float lane = __fadd_rn(__fadd_rn(__fadd_rn(p[0][l], p[1][l]), p[2][l]), p[3][l]);
-            fin = __fadd_rn(fin, lane);
-        }
-        result = fin;
-    }
-    return result;
-}
 
 // One thread per point: transpose to channel-major and compute ||x||^2 with the exact recipe.
 // Two sources (x2 != nullptr): channel c < split comes from x, the rest from row p of x2 [B*N, C - split] - the feature rows
@@ -1106,6 +985,46 @@ void launch_main(const float* xT, const float* xx, int64_t B, int N, int C, int 
 
 }  // namespace
 
+// Which form of the main kernel a call takes decides the table's layout (one place: the fused producers of apply_knn.h ask it too)
+struct KnnLayout { int il4; bool mf8; int64_t Cpad; };
+static KnnLayout knn_layout(int64_t N, int64_t C) {
+    // the matrix-core form of the main kernel (512 < N <= 2048, N % 16 == 0) reads the table with its channels interleaved in fours
+    static const bool valu = getenv("SVNET_KNN_MFMA") == nullptr && !SVNET_KNN_FORCE_MF;
+    static const bool mf8_on = getenv("SVNET_KNN_NO_MF8") == nullptr && SVNET_KNN_MF8;
+    KnnLayout l;
+    l.il4 = (N > 512 && N <= 2048 && (N & 15) == 0 && !valu) ? 1 : 0;
+    l.mf8 = mf8_on && valu && N > 512 && N <= 1024 && (N & 15) == 0;              // knn_mf8_kernel: the table's clouds are C8 rows apart
+    l.Cpad = l.il4 ? ((C + 3) & ~(int64_t)3) : (l.mf8 ? (C + 7) / 8 * 8 : C);
+    return l;
+}
+
+bool svnet_knn_table_is_channel_major(int64_t N, int64_t C, int64_t* Cpad) {
+    const KnnLayout l = knn_layout(N, C);
+    if (Cpad) *Cpad = l.Cpad;
+    return !l.il4;
+}
+
+static int knn_run_main(const float* xT, const float* xx, int64_t B, int64_t N, int64_t C, int k, int64_t* idx_out, bool mf8, hipStream_t st);
+
+extern "C" int svnet_knn_table_fusable(int64_t B, int64_t N, int64_t C) {
+    return B > 0 && N > 0 && (N % 32) == 0 && C >= 8 && C <= 384 && N <= 4096 && svnet_knn_table_is_channel_major(N, C, nullptr) ? 1 : 0;
+}
+
+extern "C" int svnet_knn_from_table_f32(const void* workspace, size_t workspace_bytes, int64_t B, int64_t N, int64_t C, int k,
+                                        int64_t* idx_out, void* stream) {
+    SVNET_REQUIRE(workspace && idx_out, SVNET_E_ARG, "svnet_knn_from_table_f32: null pointer");
+    SVNET_REQUIRE(B >= 0 && N > 0 && C > 0 && k > 0 && k <= N, SVNET_E_ARG, "svnet_knn_from_table_f32: bad sizes B=%lld N=%lld C=%lld k=%d",
+                  (long long)B, (long long)N, (long long)C, k);
+    SVNET_REQUIRE(C <= 384 && N <= 4096 && k <= 64, SVNET_E_UNSUPPORTED, "svnet_knn_from_table_f32: outside C<=384, N<=4096, k<=64");
+    SVNET_REQUIRE(workspace_bytes >= svnet_knn_workspace_bytes(B, N, C), SVNET_E_WORKSPACE, "svnet_knn_from_table_f32: workspace too small");
+    const KnnLayout lay = knn_layout(N, C);
+    SVNET_REQUIRE(!lay.il4, SVNET_E_UNSUPPORTED, "svnet_knn_from_table_f32: this configuration reads an interleaved table (svnet_knn_table_fusable)");
+    if (B == 0) return SVNET_OK;
+    const float* xT = (const float*)workspace;
+    const float* xx = xT + B * N * ((C + 7) / 8 * 8);
+    return knn_run_main(xT, xx, B, N, C, k, idx_out, lay.mf8, (hipStream_t)stream);
+}
+
 extern "C" size_t svnet_knn_workspace_bytes(int64_t B, int64_t N, int64_t C) {
     if (B < 0 || N < 0 || C < 0) return 0;
     return (size_t)(B * N * ((C + 7) / 8 * 8) + B * N) * sizeof(float) + 256;     // (channels padded to a multiple of 8: whole chunks of the matrix-core form)
@@ -1141,11 +1060,9 @@ static int knn_impl(const float* x, const float* x2, int64_t split, int64_t B, i
     float* xT = (float*)workspace;
     const int64_t C8 = (C + 7) / 8 * 8;
     float* xx = xT + B * N * C8;
-    // the matrix-core form of the main kernel (512 < N <= 2048, N % 16 == 0) reads the table with its channels interleaved in fours
-    static const bool valu = getenv("SVNET_KNN_MFMA") == nullptr && !SVNET_KNN_FORCE_MF;
-    const int il4 = (N > 512 && N <= 2048 && (N & 15) == 0 && !valu) ? 1 : 0;
-    static const bool mf8_on = getenv("SVNET_KNN_NO_MF8") == nullptr && SVNET_KNN_MF8;
-    const bool mf8 = mf8_on && valu && N > 512 && N <= 1024 && (N & 15) == 0;     // knn_mf8_kernel: the table's clouds are C8 rows apart
+    const KnnLayout lay = knn_layout(N, C);
+    const int il4 = lay.il4;
+    const bool mf8 = lay.mf8;
     // one wave per workgroup: a thread walks its point's row, so every load instruction of a wave touches 64 cache lines - the kernel is
     // bound by the CUs' address units, and 32 768 points in 256-thread workgroups put four such waves on each of only 128 CUs (61 -> 47 us
     // for the four calls of a step; staging the rows through LDS with coalesced loads was slower - 33 us per call whatever C: one wave
@@ -1162,6 +1079,10 @@ static int knn_impl(const float* x, const float* x2, int64_t split, int64_t B, i
 #if SVNET_KNN_ABL == 5   // diagnostic build: the table preparation alone
     return SVNET_OK;
 #endif
+    return knn_run_main(xT, xx, B, N, C, k, idx_out, mf8, st);
+}
+
+static int knn_run_main(const float* xT, const float* xx, int64_t B, int64_t N, int64_t C, int k, int64_t* idx_out, bool mf8, hipStream_t st) {
     const int n = (int)N, c = (int)C;
     if (N <= 64) launch_main<1, 8>(xT, xx, B, n, c, k, idx_out, st);
     else if (N <= 128) launch_main<2, 8>(xT, xx, B, n, c, k, idx_out, st);

@@ -41,10 +41,17 @@ class SV_DGCNN_CLS(nn.Module):
         sink = _ops.CatSink([b.linear1.out_features for b in blocks], [b.linear2.out_features for b in blocks])
         with sink:
             v = get_graph_feature(x.unsqueeze(1), k=self.k)               # [B,N,k,3,2]
-            level = svpool(self.conv1((self.init_scalar(v), v)))
+            # (a level whose output the next level's k-NN reads prepares that k-NN's table in its apply pass: _ops.knn_table_ahead)
+            with _ops.knn_table_ahead():
+                level = svpool(self.conv1((self.init_scalar(v), v)))
             pyramid = [level]
             for block in (self.conv2, self.conv3, self.conv4):             # dynamic feature-space graph per level
-                level = svpool(block(get_graph_feature_sv(level, k=self.k)))
+                edges = get_graph_feature_sv(level, k=self.k)
+                if block is self.conv4:
+                    level = svpool(block(edges))
+                else:
+                    with _ops.knn_table_ahead():
+                        level = svpool(block(edges))
                 pyramid.append(level)
 
         # feat = svfuse(conv5(.)) is [B,N,1022] = [s | s_v]; it is only ever pooled over the points, so its two parts are pooled

@@ -87,10 +87,16 @@ class SV_DGCNN_PSEG(nn.Module):
         sink = _ops.CatSink([b.linear1.out_features for b in blocks], [b.linear2.out_features for b in blocks])
         with sink:
             v = get_graph_feature(x.unsqueeze(1), k=self.k)
-            level = svpool(self.conv1((self.init_scalar(v), v)))
+            with _ops.knn_table_ahead():                                  # (the next level's k-NN table from this level's apply pass)
+                level = svpool(self.conv1((self.init_scalar(v), v)))
             pyramid = [level]
             for block in (self.conv2, self.conv3, self.conv4):
-                level = svpool(block(get_graph_feature_sv(level, k=self.k)))
+                edges = get_graph_feature_sv(level, k=self.k)
+                if block is self.conv4:
+                    level = svpool(block(edges))
+                else:
+                    with _ops.knn_table_ahead():
+                        level = svpool(block(edges))
                 pyramid.append(level)
 
         x = sink.result(pyramid)

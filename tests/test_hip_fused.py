@@ -451,3 +451,101 @@ def test_cat_sink_with_a_layerwise_level_falls_back_to_cat(layerwise_level, hip_
         outs[use_sink] = g
     assert np.array_equal(outs[True]["out0"], outs[False]["out0"]) and np.array_equal(outs[True]["out1"], outs[False]["out1"])
     compare_case(outs[True], outs[False], 1e-4, "pyramid with a layer-wise level: sink vs no sink")
+
+
+# ----------------------------------------------------------------------------- the next level's k-NN table from the apply pass
+
+@pytest.mark.parametrize("xyz", [False, True], ids=["edge_level", "first_level"])
+@pytest.mark.parametrize("cfg", [(2, 1024, 32, 10, 20), (2, 1024, 64, 21, 20), (1, 1024, 128, 42, 20), (1, 2048, 32, 16, 40), (1, 2048, 64, 24, 40),
+                                 (3, 96, 32, 10, 8), (2, 160, 64, 21, 16), (2, 512, 8, 1, 5)],
+                         ids=["conv2", "conv3", "conv4w", "pseg2", "pseg3", "n96", "n160", "narrow"])
+def test_apply_pass_that_prepares_the_knn_table_is_bit_identical(cfg, xyz, hip_device):
+    """svnet_{edgeblock,xyzblock}_apply_knn_f32 + svnet_knn_from_table_f32 (csrc/apply_knn.h) against svnet_*_apply_f32 +
+    svnet_knn_sv_f32 on the same inputs: pooled outputs, their concatenation slices, the WHOLE k-NN workspace (channel-major table, zero
+    rows, ||x||^2 by ATen's contiguous-row recipe) and the neighbour lists, bit for bit (sv_util.py:19-25,100-101)."""
+    from svnet_amd import _lib
+    from svnet_amd._ops import _p, _stream, call
+    B, N, Os, Ov, k = cfg
+    P, C = B * N, Os + 3 * Ov
+    L = _lib.lib()
+    assert L.svnet_knn_table_fusable(B, N, C) == 1
+    g = torch.Generator().manual_seed(5 + Os + N)
+    f32 = dict(dtype=torch.float32, device=hip_device)
+    if xyz:
+        hi = torch.randn(P, Os, generator=g).to(hip_device)
+        lo = (hi.cpu() - torch.rand(P, Os, generator=g)).to(hip_device)
+    else:
+        hi = torch.randint(-200, 200, (P, Os), generator=g, dtype=torch.int32).to(hip_device)
+        lo = (hi.cpu() - torch.randint(0, 50, (P, Os), generator=g, dtype=torch.int32)).to(hip_device)
+    mv, mvn = torch.randn(P, 3, Ov, generator=g).to(hip_device), torch.randn(P, 3, Ov, generator=g).to(hip_device)
+    coef = torch.randn(4 * Os + 4 * Ov, generator=g)
+    coef[:Os] *= 0.05                                          # A1: both signs (max_k n or min_k n is the pooled one)
+    coef = coef.to(hip_device)
+    gate = torch.rand(B, Ov, generator=g).to(hip_device)
+    name = "xyzblock" if xyz else "edgeblock"
+    nbytes = L.svnet_knn_workspace_bytes(B, N, C)
+    out = {}
+    for fused in (False, True):
+        s_out, v_out = torch.empty(B, N, Os, **f32), torch.empty(B, N, 3, Ov, **f32)
+        s_cat, v_cat = torch.zeros(P, Os + 7, **f32), torch.zeros(P, 3, Ov + 5, **f32)
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=hip_device)
+        idx = torch.empty(B, N, k, dtype=torch.int64, device=hip_device)
+        args = (_p(hi), _p(lo), _p(mv), _p(mvn), _p(coef), _p(gate), P, N, Os, Ov, 0.2, _p(s_out), _p(v_out), _p(s_cat[:, 3:]), Os + 7,
+                _p(v_cat[:, :, 2:]), Ov + 5)
+        if fused:
+            call("svnet_%s_apply_knn_f32" % name, *args, _p(ws), nbytes, _stream())
+            call("svnet_knn_from_table_f32", _p(ws), nbytes, B, N, C, k, _p(idx), _stream())
+        else:
+            call("svnet_%s_apply_f32" % name, *args, _stream())
+            call("svnet_knn_sv_f32", _p(s_out), Os, _p(v_out), 3 * Ov, B, N, k, _p(idx), _p(ws), nbytes, _stream())
+        torch.cuda.synchronize()
+        out[fused] = (s_out.cpu(), v_out.cpu(), s_cat.cpu(), v_cat.cpu(), ws.cpu(), idx.cpu())
+    C8 = (C + 7) // 8 * 8
+    wa, wb = (out[f][4][:4 * (P * C8 + P)].view(torch.float32) for f in (True, False))
+    bad_t, bad_x = int((wa[:P * C8] != wb[:P * C8]).sum()), int((wa[P * C8:] != wb[P * C8:]).sum())
+    assert bad_t == 0 and bad_x == 0, "table entries that differ: %d of %d, ||x||^2: %d of %d" % (bad_t, P * C8, bad_x, P)
+    for a, b_, what in zip(out[True], out[False], ("s_out", "v_out", "s_cat", "v_cat", "knn workspace", "idx")):
+        assert torch.equal(a, b_), what
+    assert torch.equal(out[True][2][:, 3:3 + Os], out[True][0].view(P, Os)) and float(out[True][2][:, :3].abs().max()) == 0.0
+    assert int(out[True][5].min()) >= 0 and int(out[True][5].max()) < N
+
+
+def test_apply_knn_refuses_what_it_cannot_tile(hip_device):
+    from svnet_amd import _lib
+    from svnet_amd._ops import _p, _stream
+    L = _lib.lib()
+    assert L.svnet_knn_table_fusable(2, 100, 62) == 0 and L.svnet_knn_table_fusable(2, 1024, 4) == 0 and L.svnet_knn_table_fusable(2, 1024, 62) == 1
+    t = torch.zeros(64, device=hip_device)
+    rc = L.svnet_edgeblock_apply_knn_f32(_p(t), _p(t), _p(t), _p(t), _p(t), _p(t), 200, 100, 32, 10, 0.2, _p(t), _p(t), None, 0, None, 0, _p(t), 256,
+                                          _stream())
+    assert rc == -2 and b"not supported" in L.svnet_last_error()
+
+
+@pytest.mark.parametrize("model_name,B,N,k", [("sv_dgcnn_cls", 2, 128, 8), ("sv_dgcnn_pseg", 2, 64, 6)])
+def test_models_give_the_same_bits_with_and_without_the_table_ahead(model_name, B, N, k, hip_device, monkeypatch):
+    """The callers with config.KNN_TABLE_AHEAD on and off: logits and loss identical, every parameter gradient to the run-to-run noise
+    of its atomics (the prepared table is the table), and the switch does route the k-NN: three calls from a prepared table per step when on, none when off."""
+    from svnet_amd import _ops, config
+    from oracle import params as oparams
+    from tests.test_hip_train_parity import build_model, hip_step
+    x, l, y = C.model_inputs("ahead_" + model_name, model_name, B, N)
+    state = oparams.synthetic_params(model_name, binary=True, seed=C.SEED)
+    taken = []
+    real_take = _ops.knn_table_ahead.take
+    monkeypatch.setattr(_ops.knn_table_ahead, "take", staticmethod(lambda s_, v_: taken.append(real_take(s_, v_)) or taken[-1]))
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(config, "KNN_TABLE_AHEAD", on)
+        del taken[:]
+        m = build_model(model_name, True, k, hip_device, state).train()
+        logits, loss, got, _ = hip_step(m, x, l, y, hip_device)
+        torch.cuda.synchronize()
+        assert [t is not None for t in taken] == [on] * 3, taken
+        res[on] = (logits, loss, got)
+    assert np.array_equal(res[True][0], res[False][0]) and res[True][1] == res[False][1]
+    # (gradients: the backward never sees the table - the same kernels on the same bits, but their float atomics arrive in another order
+    #  from run to run, and cancelling sums such as a binarized layer's scale gradient show that at 1e-2 of their own size)
+    gmax = max(float(np.abs(g_).max()) for g_ in res[False][2].values())
+    for n, g_ in res[True][2].items():
+        ref = res[False][2][n]
+        assert float(np.abs(g_ - ref).max()) <= 1e-4 * float(np.abs(ref).max()) + 1e-5 * gmax, n
