@@ -47,7 +47,7 @@ int svnet_slices_sum_f64(double* buf, int64_t L, void* stream);
  * changes its required length (200: sliced accumulators, SVNET_SLICED_LEN; 400: this header; 401: the totals of a sliced accumulator are
  * written by its consumer, svnet_slices_sum_*; 402: GX of svnet_v2s_bwd_*, gw of svnet_xyzblock_bwd_f32 and col_sum of svnet_gemm_f32 are sliced accumulators; 403: svnet_binweight_grad_f32 takes sliced inputs).  svnet_version() returns the value the
  * library was BUILT with: a caller compiled against another header must refuse to run (svnet_amd/_lib.py does).                   */
-#define SVNET_ABI_VERSION 415
+#define SVNET_ABI_VERSION 416
 int svnet_version(void);
 const char* svnet_last_error(void);
 
@@ -247,6 +247,30 @@ int svnet_edgeblock_apply_f32(const int32_t* n_max, const int32_t* n_min, const 
                               const float* coef, const float* gate, int64_t P, int64_t N, int64_t Os, int64_t Ov,
                               float slope, float* s_out, float* v_out, float* s_cat, int64_t s_ld, float* v_cat, int64_t v_ld,
                               void* stream);
+
+/* Everything between a fused level's edge pass and the next level's k-NN in ONE launch: the coefficients (svnet_*_coeffs_f32, gate MLP
+ * included), the apply pass (svnet_*_apply_f32) and, with knn_workspace, the next k-NN's table (svnet_*_apply_knn_f32).  Three dependent
+ * launches of latency-bound work per level sat on the forward's critical path; here every workgroup (32 points of one cloud) derives
+ * the ~2 (Os + Ov) coefficients from the statistic slices and its cloud's gate itself - the same expressions as the separate kernels,
+ * bit-identical outputs - and workgroup 0 alone writes coef, the running statistics and the counters.  Needs N % 32 == 0, Os <= 256,
+ * Ov <= 256 (svnet_block_tail_supported); stat1 = the scalar path's sums: int64 slices of (sum n, sum n^2) for the edge block
+ * (scale1 required), fp64 slices of (sum y, sum y^2) for the first level (scale1 NULL); hi / lo = n_max / n_min (int32) or y_max / y_min. */
+typedef struct svnet_block_tail_desc {
+    const void* stat1; const double* stat_v; int64_t E, Os, Ov;
+    const float* scale1;
+    const float* gamma1; const float* beta1; float* running_mean1; float* running_var1;
+    const float* gamma2; const float* beta2; float* running_mean2; float* running_var2;
+    int training; float eps, momentum;
+    float* coef; int64_t* num_batches_tracked1; int64_t* num_batches_tracked2;
+    svnet_gate_fwd_job gate;
+    const void* hi; const void* lo; const float* mv; const float* mvn;
+    int64_t P, N; float slope;
+    float* s_out; float* v_out; float* s_cat; int64_t s_ld; float* v_cat; int64_t v_ld;
+    void* knn_workspace; size_t knn_workspace_bytes;          /* NULL / 0: no table */
+} svnet_block_tail_desc;
+int svnet_block_tail_supported(int64_t P, int64_t N, int64_t Os, int64_t Ov, int with_knn_table);
+int svnet_edgeblock_tail_f32(const svnet_block_tail_desc* desc, void* stream);
+int svnet_xyzblock_tail_f32(const svnet_block_tail_desc* desc, void* stream);
 
 /* Backward of the fused edge block: a point-level prelude reduces the batch-statistic terms of both BatchNorms,
  * then the edge pass produces all gradients from the point tables and the n16 / planes the forward kept

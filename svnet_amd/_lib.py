@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVNET_DIAG_LIB") or os.path.join(_HERE, "libsvnet_hip.so")    # (SVNET_DIAG_LIB: an ablation build, tools/ only)
 _lib = None
-ABI_VERSION = 415       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
+ABI_VERSION = 416       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
 
 c_p = ctypes.c_void_p
 c_i64 = ctypes.c_int64
@@ -46,6 +46,19 @@ class GateFwdJob(ctypes.Structure):
     """struct svnet_gate_fwd_job (include/svnet_hip.h): a gate MLP run beside a coefficient launch."""
     _fields_ = [("gin", c_p), ("gin_f64", c_p), ("gin_out", c_p), ("in_scale", c_f), ("W0", c_p), ("W2", c_p),
                 ("B", c_i64), ("Cin", c_i64), ("H", c_i64), ("Ov", c_i64), ("h", c_p), ("gate", c_p), ("rows", c_p), ("R", c_i64)]
+
+
+class BlockTailDesc(ctypes.Structure):
+    """struct svnet_block_tail_desc (include/svnet_hip.h): coefficients + gate MLP + apply (+ k-NN table) of a fused level in one launch."""
+    _fields_ = [("stat1", c_p), ("stat_v", c_p), ("E", c_i64), ("Os", c_i64), ("Ov", c_i64), ("scale1", c_p),
+                ("gamma1", c_p), ("beta1", c_p), ("running_mean1", c_p), ("running_var1", c_p),
+                ("gamma2", c_p), ("beta2", c_p), ("running_mean2", c_p), ("running_var2", c_p),
+                ("training", c_int), ("eps", c_f), ("momentum", c_f),
+                ("coef", c_p), ("num_batches_tracked1", c_p), ("num_batches_tracked2", c_p),
+                ("gate", GateFwdJob),
+                ("hi", c_p), ("lo", c_p), ("mv", c_p), ("mvn", c_p), ("P", c_i64), ("N", c_i64), ("slope", c_f),
+                ("s_out", c_p), ("v_out", c_p), ("s_cat", c_p), ("s_ld", c_i64), ("v_cat", c_p), ("v_ld", c_i64),
+                ("knn_workspace", c_p), ("knn_workspace_bytes", c_sz)]
 
 
 class GateBwdJob(ctypes.Structure):
@@ -144,6 +157,9 @@ SIGNATURES = {
     "svnet_knn_f32": (c_int, [c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p, c_p, c_sz, c_p]),
     "svnet_knn_sv_f32": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_int, c_p, c_p, c_sz, c_p]),
     "svnet_knn_table_fusable": (c_int, [c_i64, c_i64, c_i64]),
+    "svnet_block_tail_supported": (c_int, [c_i64, c_i64, c_i64, c_i64, c_int]),
+    "svnet_edgeblock_tail_f32": (c_int, [c_p, c_p]),
+    "svnet_xyzblock_tail_f32": (c_int, [c_p, c_p]),
     "svnet_knn_from_table_f32": (c_int, [c_p, c_sz, c_i64, c_i64, c_i64, c_int, c_p, c_p]),
     "svnet_edge_xyz_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_int, c_p, c_p]),
     "svnet_edge_diffcat_fwd_f32": (c_int, [c_p, c_p, c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_p, c_p]),

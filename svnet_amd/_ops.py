@@ -117,6 +117,29 @@ def knn(x, k):
     return idx
 
 
+def _block_tail(entry, P, N, E, Os, Ov, stat1, stat_v, sc1, g1, b1, rm1, rv1, g2, b2, rm2, rv2, training, coef, nbt1, nbt2, job, hi, lo, mv, mvn,
+                s_out, v_out, slot, kws):
+    """svnet_{edgeblock,xyzblock}_tail_f32: coefficients + gate MLP + apply (+ the k-NN table kws) of a fused level as ONE launch.
+    False = not taken (switch off / shape not supported): the caller issues the separate launches."""
+    if not config.FUSE_BLOCK_TAIL or not _lib.lib().svnet_block_tail_supported(P, N, Os, Ov, 1 if kws is not None else 0):
+        return False
+    d = _lib.BlockTailDesc()
+    d.stat1, d.stat_v, d.E, d.Os, d.Ov, d.scale1 = _p(stat1), _p(stat_v), E, Os, Ov, _p(sc1)
+    d.gamma1, d.beta1, d.running_mean1, d.running_var1 = _p(g1), _p(b1), _p(rm1), _p(rv1)
+    d.gamma2, d.beta2, d.running_mean2, d.running_var2 = _p(g2), _p(b2), _p(rm2), _p(rv2)
+    d.training, d.eps, d.momentum = int(training), BN_EPS, BN_MOMENTUM
+    d.coef, d.num_batches_tracked1, d.num_batches_tracked2 = _p(coef), _p(nbt1), _p(nbt2)
+    d.gate = job
+    d.hi, d.lo, d.mv, d.mvn, d.P, d.N, d.slope = _p(hi), _p(lo), _p(mv), _p(mvn), P, N, 0.2
+    d.s_out, d.v_out = _p(s_out), _p(v_out)
+    if slot is not None:
+        d.s_cat, d.s_ld, d.v_cat, d.v_ld = slot
+    if kws is not None:
+        d.knn_workspace, d.knn_workspace_bytes = _p(kws), kws.numel()
+    call(entry, ctypes.byref(d), _stream())
+    return True
+
+
 class knn_table_ahead:
     """`with knn_table_ahead():` around a fused level whose pooled (s, v) is read next by get_graph_feature_sv (sv_dgcnn_cls.py:55-65):
     the level's apply pass then also writes the candidate table of that k-NN (svnet_*_apply_knn_f32: the k-NN is on the forward's
@@ -1889,20 +1912,25 @@ class EdgeBlock(torch.autograd.Function):
         job = _lib.GateFwdJob(None, _p(gate_sum), _p(gin), 1.0 / float(N * k), _p(Wg0c), _p(Wg2c), B, 2 * Cs, H, Ov, _p(h), _p(gate))
 
         coef = torch.empty((4 * Os + 4 * Ov,), **f32)
-        call("svnet_edgeblock_coeffs_f32", _p(stat_n), _p(stat_v), E, Os, Ov, _p(sc1), _p(g1), _p(b1), _p(rm1), _p(rv1),
-             _p(g2), _p(b2), _p(rm2), _p(rv2), int(training), BN_EPS, BN_MOMENTUM, _p(coef), _p(nbt1), _p(nbt2), ctypes.byref(job), _stream())
-        _tap_act(Wg0, 2, h)
         s_out = torch.empty((B, N, Os), **f32)
         v_out = torch.empty((B, N, 3, Ov), **f32)
         slot = _SINK.slot(B, N, Os, Ov, dev) if _SINK is not None else None
         kws = knn_table_ahead.workspace(B, N, Os, Ov, dev)
-        if kws is not None:
-            call("svnet_edgeblock_apply_knn_f32", _p(n_max), _p(n_min), _p(mv), _p(mvn), _p(coef), _p(gate), P, N, Os, Ov, 0.2, _p(s_out),
-                 _p(v_out), *(slot if slot is not None else (None, 0, None, 0)), _p(kws), kws.numel(), _stream())
-            knn_table_ahead.table = (s_out.data_ptr(), v_out.data_ptr(), kws, B, N, Os + 3 * Ov)
+        if _block_tail("svnet_edgeblock_tail_f32", P, N, E, Os, Ov, stat_n, stat_v, sc1, g1, b1, rm1, rv1, g2, b2, rm2, rv2, training, coef,
+                       nbt1, nbt2, job, n_max, n_min, mv, mvn, s_out, v_out, slot, kws):
+            pass        # coefficients + gate MLP + apply (+ the next k-NN's table) in one launch
         else:
-            call("svnet_edgeblock_apply_f32", _p(n_max), _p(n_min), _p(mv), _p(mvn), _p(coef), _p(gate), P, N, Os, Ov, 0.2, _p(s_out),
-                 _p(v_out), *(slot if slot is not None else (None, 0, None, 0)), _stream())
+            call("svnet_edgeblock_coeffs_f32", _p(stat_n), _p(stat_v), E, Os, Ov, _p(sc1), _p(g1), _p(b1), _p(rm1), _p(rv1),
+                 _p(g2), _p(b2), _p(rm2), _p(rv2), int(training), BN_EPS, BN_MOMENTUM, _p(coef), _p(nbt1), _p(nbt2), ctypes.byref(job), _stream())
+            if kws is not None:
+                call("svnet_edgeblock_apply_knn_f32", _p(n_max), _p(n_min), _p(mv), _p(mvn), _p(coef), _p(gate), P, N, Os, Ov, 0.2, _p(s_out),
+                     _p(v_out), *(slot if slot is not None else (None, 0, None, 0)), _p(kws), kws.numel(), _stream())
+            else:
+                call("svnet_edgeblock_apply_f32", _p(n_max), _p(n_min), _p(mv), _p(mvn), _p(coef), _p(gate), P, N, Os, Ov, 0.2, _p(s_out),
+                     _p(v_out), *(slot if slot is not None else (None, 0, None, 0)), _stream())
+        if kws is not None:
+            knn_table_ahead.table = (s_out.data_ptr(), v_out.data_ptr(), kws, B, N, Os + 3 * Ov)
+        _tap_act(Wg0, 2, h)
         s_view, v_view = _SINK.wrote(s_out, v_out) if slot is not None else (None, None)
         if TAP is not None:      # the pooled slot: BatchNorm + LeakyReLU is increasing (slope coef[o] >= 0: max_k n) or decreasing (min_k n)
             TAP["pools"].append(torch.where(coef[:Os].view(1, Os) >= 0, slot_max, slot_min))
@@ -2127,20 +2155,25 @@ class XyzBlock(torch.autograd.Function):
         job = _lib.GateFwdJob(None, _p(gate_sum), _p(gin), 1.0 / float(N * k), _p(Wg0c), _p(Wg2c), B, NG, H, Ov, _p(h), _p(gate))   # (beside the coefficients)
 
         coef = torch.empty((4 * Os + 4 * Ov,), **f32)
-        call("svnet_xyzblock_coeffs_f32", _p(stat_y), _p(stat_v), E, Os, Ov, _p(g1), _p(b1), _p(rm1), _p(rv1), _p(g2), _p(b2), _p(rm2),
-             _p(rv2), int(training), BN_EPS, BN_MOMENTUM, _p(coef), _p(nbt1), _p(nbt2), ctypes.byref(job), _stream())
-        _tap_act(Wg0, 2, h)
         s_out = torch.empty((B, N, Os), **f32)
         v_out = torch.empty((B, N, 3, Ov), **f32)
         slot = _SINK.slot(B, N, Os, Ov, dev) if _SINK is not None else None
         kws = knn_table_ahead.workspace(B, N, Os, Ov, dev)
-        if kws is not None:
-            call("svnet_xyzblock_apply_knn_f32", _p(y_max), _p(y_min), _p(mv), _p(mvn), _p(coef), _p(gate), P, N, Os, Ov, 0.2, _p(s_out),
-                 _p(v_out), *(slot if slot is not None else (None, 0, None, 0)), _p(kws), kws.numel(), _stream())
-            knn_table_ahead.table = (s_out.data_ptr(), v_out.data_ptr(), kws, B, N, Os + 3 * Ov)
+        if _block_tail("svnet_xyzblock_tail_f32", P, N, E, Os, Ov, stat_y, stat_v, None, g1, b1, rm1, rv1, g2, b2, rm2, rv2, training, coef,
+                       nbt1, nbt2, job, y_max, y_min, mv, mvn, s_out, v_out, slot, kws):
+            pass
         else:
-            call("svnet_xyzblock_apply_f32", _p(y_max), _p(y_min), _p(mv), _p(mvn), _p(coef), _p(gate), P, N, Os, Ov, 0.2, _p(s_out), _p(v_out),
-                 *(slot if slot is not None else (None, 0, None, 0)), _stream())
+            call("svnet_xyzblock_coeffs_f32", _p(stat_y), _p(stat_v), E, Os, Ov, _p(g1), _p(b1), _p(rm1), _p(rv1), _p(g2), _p(b2), _p(rm2),
+                 _p(rv2), int(training), BN_EPS, BN_MOMENTUM, _p(coef), _p(nbt1), _p(nbt2), ctypes.byref(job), _stream())
+            if kws is not None:
+                call("svnet_xyzblock_apply_knn_f32", _p(y_max), _p(y_min), _p(mv), _p(mvn), _p(coef), _p(gate), P, N, Os, Ov, 0.2, _p(s_out),
+                     _p(v_out), *(slot if slot is not None else (None, 0, None, 0)), _p(kws), kws.numel(), _stream())
+            else:
+                call("svnet_xyzblock_apply_f32", _p(y_max), _p(y_min), _p(mv), _p(mvn), _p(coef), _p(gate), P, N, Os, Ov, 0.2, _p(s_out), _p(v_out),
+                     *(slot if slot is not None else (None, 0, None, 0)), _stream())
+        if kws is not None:
+            knn_table_ahead.table = (s_out.data_ptr(), v_out.data_ptr(), kws, B, N, Os + 3 * Ov)
+        _tap_act(Wg0, 2, h)
         s_view, v_view = _SINK.wrote(s_out, v_out) if slot is not None else (None, None)
         if TAP is not None:
             TAP["pools"].append(torch.where(coef[:Os].view(1, Os) >= 0, slot_max, slot_min))

@@ -87,3 +87,5 @@ GATE_MEAN_INSIDE = True
 EDGE_DENSE_WEIGHTS = True
 # A fused level followed by get_graph_feature_sv prepares that k-NN's candidate table in its apply pass (_ops.knn_table_ahead)
 KNN_TABLE_AHEAD = True
+# ... and the coefficients + gate MLP + apply pass of a fused level are ONE launch (svnet_*_tail_f32) instead of two on the critical path
+FUSE_BLOCK_TAIL = True

@@ -25,7 +25,7 @@ __device__ __forceinline__ void apply_knn_tiles(const Math& m, int64_t P, int64_
     const int64_t tiles = P / TP;                                                 // (N % TP == 0, checked on the host: a tile lies in one cloud)
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int64_t p0 = tile * TP, b = p0 / N, n0 = p0 - b * N;
-        if (tile != (int64_t)blockIdx.x) __syncthreads();                         // the previous tile has been read
+        if (xT && tile != (int64_t)blockIdx.x) __syncthreads();                   // the previous tile has been read
         // the tile's TP x Os scalars and TP x 3 Ov vector entries are contiguous runs of s_out / v_out: flat element loops (coalesced
         // whatever the widths; four independent rows of loads in flight per thread), the (row, column) cursor advanced without divisions
         {
@@ -48,7 +48,7 @@ __device__ __forceinline__ void apply_knn_tiles(const Math& m, int64_t P, int64_
                         const int64_t p = p0 + rr[u];
                         s_out[p * Os + cc[u]] = z[u];
                         if (s_cat) s_cat[p * s_ld + cc[u]] = z[u];
-                        staged[rr[u] * LD + cc[u]] = z[u];
+                        if (xT) staged[rr[u] * LD + cc[u]] = z[u];
                     }
                 }
             }
@@ -75,11 +75,12 @@ __device__ __forceinline__ void apply_knn_tiles(const Math& m, int64_t P, int64_
                         const int q = cc[u], dd = q >= 2 * Ov ? 2 : (q >= Ov ? 1 : 0);
                         v_out[p * 3 * Ov + q] = z[u];
                         if (v_cat) v_cat[(p * 3 + dd) * v_ld + (q - dd * Ov)] = z[u];
-                        staged[rr[u] * LD + Os + q] = z[u];
+                        if (xT) staged[rr[u] * LD + Os + q] = z[u];
                     }
                 }
             }
         }
+        if (!xT) continue;                                                        // (no table asked for: the apply pass alone; uniform)
         __syncthreads();
         if (wave == 0 && lane < TP) {
             struct Src { const float* a; __device__ __forceinline__ float operator[](int64_t off) const { return a[off]; } } src = {staged + lane * LD};

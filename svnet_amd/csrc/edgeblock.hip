@@ -640,65 +640,74 @@ __global__ __launch_bounds__(256, 4) void edgeblock_fwd2_kernel(FwdArgs fa) {
 //   scalar: y = A1*n + B1 with A1 = gamma*scale*invstd_y,  B1 = beta - gamma*mean_y*invstd_y   (y_pre = scale*n)
 //   vector: q(n') = Av + Bv/n' with Av = gamma'*invstd', Bv = beta' - gamma'*mean'*invstd'
 // coef layout: [A1 (Os) | B1 (Os) | mean_y (Os) | invstd_y (Os) | Av (Ov) | Bv (Ov) | mean' (Ov) | invstd' (Ov)]
-__global__ void edgeblock_coeffs_kernel(const long long* __restrict__ stat_n, const double* __restrict__ stat_v, int64_t E, int Os,
-                                        int Ov, const float* __restrict__ scale1, const float* __restrict__ g1,
-                                        const float* __restrict__ b1, float* __restrict__ rm1, float* __restrict__ rv1,
-                                        const float* __restrict__ g2, const float* __restrict__ b2, float* __restrict__ rm2,
-                                        float* __restrict__ rv2, int training, float eps, float momentum,
-                                        float* __restrict__ coef, long long* __restrict__ nbt1, long long* __restrict__ nbt2,
-                                        svnet_gate_fwd_job job, int coef_blocks) {
-    if ((int)blockIdx.x >= coef_blocks) { svnet_gate_fwd_block(job, (int)blockIdx.x - coef_blocks); return; }   // the gate MLP beside the coefficients
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && training) {
-        if (nbt1) *nbt1 += 1;
-        if (nbt2) *nbt2 += 1;
-    }
-    float* A1 = coef; float* B1 = coef + Os; float* MY = coef + 2 * Os; float* IY = coef + 3 * Os;
-    float* Av = coef + 4 * Os; float* Bv = Av + Ov; float* MV = Av + 2 * Ov; float* IV = Av + 3 * Ov;
+struct EdgeCoefArgs {
+    const long long* stat_n; const double* stat_v; int64_t E; int Os, Ov;
+    const float* scale1; const float* g1; const float* b1; float* rm1; float* rv1;
+    const float* g2; const float* b2; float* rm2; float* rv2;
+    int training; float eps, momentum;
+};
+// channel c of both coefficient sets into `out` (the coef layout; global memory or a workgroup's LDS copy).  commit: this caller also
+// updates the running statistics (exactly one workgroup of a launch does).  One body for the coefficient kernel and the tail kernel.
+__device__ __forceinline__ void edge_coefs_channel(const EdgeCoefArgs& a, int c, bool commit, float* out) {
+    const int Os = a.Os, Ov = a.Ov;
+    const int64_t E = a.E;
+    float* A1 = out; float* B1 = out + Os; float* MY = out + 2 * Os; float* IY = out + 3 * Os;
+    float* Av = out + 4 * Os; float* Bv = Av + Ov; float* MV = Av + 2 * Ov; float* IV = Av + 3 * Ov;
     if (c < Os) {
         float mean, invstd;
-        if (training) {
-            const double sc = (double)scale1[c];
+        if (a.training) {
+            const double sc = (double)a.scale1[c];
             long long sn1 = 0, sn2 = 0;                        // the forward kernel's slices (exact integers: any order)
-            for (int sl = 0; sl < SVNET_RED_SLICES; ++sl) { sn1 += stat_n[sl * 2 * Os + c]; sn2 += stat_n[sl * 2 * Os + Os + c]; }
+            for (int sl = 0; sl < SVNET_RED_SLICES; ++sl) { sn1 += a.stat_n[sl * 2 * Os + c]; sn2 += a.stat_n[sl * 2 * Os + Os + c]; }
             const double mn = (double)sn1 / (double)E;
             double var_n = (double)sn2 / (double)E - mn * mn;
             if (var_n < 0.0) var_n = 0.0;
             const double m = sc * mn, var = sc * sc * var_n;
             mean = (float)m;
-            invstd = (float)(1.0 / sqrt(var + (double)eps));
-            if (rm1) rm1[c] = (1.f - momentum) * rm1[c] + momentum * mean;
-            if (rv1) rv1[c] = (1.f - momentum) * rv1[c] + momentum * (float)(E > 1 ? var * ((double)E / (double)(E - 1)) : var);
+            invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+            if (commit && a.rm1) a.rm1[c] = (1.f - a.momentum) * a.rm1[c] + a.momentum * mean;
+            if (commit && a.rv1) a.rv1[c] = (1.f - a.momentum) * a.rv1[c] + a.momentum * (float)(E > 1 ? var * ((double)E / (double)(E - 1)) : var);
         } else {
-            mean = rm1[c];
-            invstd = 1.f / sqrtf(rv1[c] + eps);
+            mean = a.rm1[c];
+            invstd = 1.f / sqrtf(a.rv1[c] + a.eps);
         }
-        A1[c] = g1[c] * scale1[c] * invstd;
-        B1[c] = b1[c] - g1[c] * mean * invstd;
+        A1[c] = a.g1[c] * a.scale1[c] * invstd;
+        B1[c] = a.b1[c] - a.g1[c] * mean * invstd;
         MY[c] = mean;
         IY[c] = invstd;
     }
     if (c < Ov) {
         float mean, invstd;
-        if (training) {
+        if (a.training) {
             double sv1 = 0.0, sv2 = 0.0;
-            for (int sl = 0; sl < SVNET_RED_SLICES; ++sl) { sv1 += stat_v[sl * 2 * Ov + c]; sv2 += stat_v[sl * 2 * Ov + Ov + c]; }
+            for (int sl = 0; sl < SVNET_RED_SLICES; ++sl) { sv1 += a.stat_v[sl * 2 * Ov + c]; sv2 += a.stat_v[sl * 2 * Ov + Ov + c]; }
             const double m = sv1 / (double)E;
             double var = sv2 / (double)E - m * m;
             if (var < 0.0) var = 0.0;
             mean = (float)m;
-            invstd = (float)(1.0 / sqrt(var + (double)eps));
-            if (rm2) rm2[c] = (1.f - momentum) * rm2[c] + momentum * mean;
-            if (rv2) rv2[c] = (1.f - momentum) * rv2[c] + momentum * (float)(E > 1 ? var * ((double)E / (double)(E - 1)) : var);
+            invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+            if (commit && a.rm2) a.rm2[c] = (1.f - a.momentum) * a.rm2[c] + a.momentum * mean;
+            if (commit && a.rv2) a.rv2[c] = (1.f - a.momentum) * a.rv2[c] + a.momentum * (float)(E > 1 ? var * ((double)E / (double)(E - 1)) : var);
         } else {
-            mean = rm2[c];
-            invstd = 1.f / sqrtf(rv2[c] + eps);
+            mean = a.rm2[c];
+            invstd = 1.f / sqrtf(a.rv2[c] + a.eps);
         }
-        Av[c] = g2[c] * invstd;
-        Bv[c] = b2[c] - g2[c] * mean * invstd;
+        Av[c] = a.g2[c] * invstd;
+        Bv[c] = a.b2[c] - a.g2[c] * mean * invstd;
         MV[c] = mean;
         IV[c] = invstd;
     }
+}
+
+__global__ void edgeblock_coeffs_kernel(EdgeCoefArgs a, float* __restrict__ coef, long long* __restrict__ nbt1, long long* __restrict__ nbt2,
+                                        svnet_gate_fwd_job job, int coef_blocks) {
+    if ((int)blockIdx.x >= coef_blocks) { svnet_gate_fwd_block(job, (int)blockIdx.x - coef_blocks); return; }   // the gate MLP beside the coefficients
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && a.training) {
+        if (nbt1) *nbt1 += 1;
+        if (nbt2) *nbt2 += 1;
+    }
+    edge_coefs_channel(a, c, true, coef);
 }
 
 // Pooled outputs: s_out = lrelu(A1 * (A1 >= 0 ? n_max : n_min) + B1); v_out = gate * (Av*mv + Bv*mvn).
@@ -760,6 +769,35 @@ __global__ __launch_bounds__(256) void edgeblock_apply_knn_kernel(const int32_t*
     extern __shared__ float apply_knn_rows[];
     const EdgeApplyMath m = {n_max, n_min, mv, mvn, coef, coef + Os, coef + 4 * Os, coef + 4 * Os + Ov, gate, Os, Ov, slope};
     apply_knn_tiles<APPLY_KNN_TP>(m, P, N, Os, Ov, s_out, v_out, s_cat, s_ld, v_cat, v_ld, xT, xx, Cpad, apply_knn_rows);
+}
+
+// ---- coefficients + gate MLP + apply (+ the next k-NN's table) in one launch (svnet_hip.h: svnet_block_tail_desc).  A workgroup = one
+// tile of APPLY_KNN_TP points of cloud b: its 256 threads derive the coefficients into LDS (thread c: channel c of both sets, as the
+// coefficient kernel's threads do), run cloud b's gate MLP (every workgroup of the cloud writes the same h / gin / gate values), then the
+// apply pass reads both from there.  Workgroup 0 alone commits: coef, running statistics, counters.
+__global__ __launch_bounds__(256) void edgeblock_tail_kernel(EdgeCoefArgs ca, float* __restrict__ coef, long long* __restrict__ nbt1,
+                                                             long long* __restrict__ nbt2, svnet_gate_fwd_job job,
+                                                             const int32_t* __restrict__ n_max, const int32_t* __restrict__ n_min,
+                                                             const float* __restrict__ mv, const float* __restrict__ mvn, int64_t P, int64_t N,
+                                                             float slope, float* __restrict__ s_out, float* __restrict__ v_out,
+                                                             float* __restrict__ s_cat, int64_t s_ld, float* __restrict__ v_cat, int64_t v_ld,
+                                                             float* __restrict__ xT, float* __restrict__ xx, int64_t Cpad) {
+    extern __shared__ float tail_lds[];                                  // [coef: 4 Os + 4 Ov (rounded to 4) | the tile's rows]
+    const int Os = ca.Os, Ov = ca.Ov;
+    const int ncoef = (4 * Os + 4 * Ov + 3) & ~3;
+    const bool first = blockIdx.x == 0;
+    const int64_t b = ((int64_t)blockIdx.x * APPLY_KNN_TP) / N;
+    if (first && threadIdx.x == 0 && ca.training) {
+        if (nbt1) *nbt1 += 1;
+        if (nbt2) *nbt2 += 1;
+    }
+    edge_coefs_channel(ca, (int)threadIdx.x, first, tail_lds);
+    svnet_gate_fwd_block(job, (int)b);
+    __syncthreads();                                                     // the coefficients in LDS, the cloud's gate in global memory
+    if (first)
+        for (int i = threadIdx.x; i < 4 * Os + 4 * Ov; i += blockDim.x) coef[i] = tail_lds[i];
+    const EdgeApplyMath m = {n_max, n_min, mv, mvn, tail_lds, tail_lds + Os, tail_lds + 4 * Os, tail_lds + 4 * Os + Ov, job.gate, Os, Ov, slope};
+    apply_knn_tiles<APPLY_KNN_TP>(m, P, N, Os, Ov, s_out, v_out, s_cat, s_ld, v_cat, v_ld, xT, xx, Cpad, tail_lds + ncoef);
 }
 
 }  // namespace
@@ -830,10 +868,10 @@ extern "C" int svnet_edgeblock_coeffs_f32(const int64_t* stat_n, const double* s
     SVNET_REQUIRE(!gate_job || svnet_gate_fwd_job_ok(gate_job), SVNET_E_ARG, "svnet_edgeblock_coeffs_f32: bad gate job");
     const int coef_blocks = (int)svnet_cdiv(n, 256);
     const svnet_gate_fwd_job job = gate_job ? *gate_job : svnet_gate_fwd_job{};
+    const EdgeCoefArgs ca = {reinterpret_cast<const long long*>(stat_n), stat_v, E, (int)Os, (int)Ov, scale1, gamma1, beta1, running_mean1,
+                             running_var1, gamma2, beta2, running_mean2, running_var2, training, eps, momentum};
     hipLaunchKernelGGL(edgeblock_coeffs_kernel, dim3((unsigned)(coef_blocks + (gate_job ? gate_job->B : 0))), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const long long*>(stat_n), stat_v, E, (int)Os, (int)Ov, scale1, gamma1, beta1, running_mean1,
-                       running_var1, gamma2, beta2, running_mean2, running_var2, training, eps, momentum, coef,
-                       reinterpret_cast<long long*>(num_batches_tracked1), reinterpret_cast<long long*>(num_batches_tracked2), job, coef_blocks);
+                       ca, coef, reinterpret_cast<long long*>(num_batches_tracked1), reinterpret_cast<long long*>(num_batches_tracked2), job, coef_blocks);
     SVNET_CHECK_LAUNCH("edgeblock_coeffs_kernel");
     return SVNET_OK;
 }
@@ -869,5 +907,51 @@ extern "C" int svnet_edgeblock_apply_knn_f32(const int32_t* n_max, const int32_t
     hipLaunchKernelGGL(edgeblock_apply_knn_kernel, dim3((unsigned)(P / APPLY_KNN_TP)), dim3(256), apply_knn_lds_bytes(Os, Ov), (hipStream_t)stream,
                        n_max, n_min, mv, mvn, coef, gate, P, N, (int)Os, (int)Ov, slope, s_out, v_out, s_cat, s_ld, v_cat, v_ld, xT, xx, Cpad);
     SVNET_CHECK_LAUNCH("edgeblock_apply_knn_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_block_tail_supported(int64_t P, int64_t N, int64_t Os, int64_t Ov, int with_knn_table) {
+    if (!(P > 0 && N > 0 && P % N == 0 && N % APPLY_KNN_TP == 0 && Os > 0 && Os <= 256 && Ov > 0 && Ov <= 256)) return 0;
+    int64_t Cpad = 0;
+    return (!with_knn_table || apply_knn_supported(P, N, Os, Ov, &Cpad)) ? 1 : 0;
+}
+
+// the checks both tail entry points share; returns the launch's dynamic LDS bytes through *lds and the table pointers
+static int block_tail_check(const svnet_block_tail_desc& d, const char* who, size_t* lds, float** xT, float** xx, int64_t* Cpad) {
+    SVNET_REQUIRE(d.hi && d.lo && d.mv && d.mvn && d.coef && d.s_out && d.v_out && d.gamma1 && d.beta1 && d.gamma2 && d.beta2, SVNET_E_ARG,
+                  "%s: null pointer", who);
+    SVNET_REQUIRE(d.training ? (d.stat1 && d.stat_v) : (d.running_mean1 && d.running_var1 && d.running_mean2 && d.running_var2), SVNET_E_ARG,
+                  "%s: missing statistics", who);
+    SVNET_REQUIRE(svnet_gate_fwd_job_ok(&d.gate) && d.gate.Ov == d.Ov && d.gate.B * d.N == d.P, SVNET_E_ARG, "%s: bad gate job", who);
+    SVNET_REQUIRE((!d.s_cat || d.s_ld >= d.Os) && (!d.v_cat || d.v_ld >= d.Ov), SVNET_E_ARG, "%s: concatenation row shorter than the slice", who);
+    SVNET_REQUIRE(svnet_block_tail_supported(d.P, d.N, d.Os, d.Ov, d.knn_workspace != nullptr), SVNET_E_UNSUPPORTED,
+                  "%s: P=%lld N=%lld Os=%lld Ov=%lld not supported (svnet_block_tail_supported)", who, (long long)d.P, (long long)d.N,
+                  (long long)d.Os, (long long)d.Ov);
+    *xT = nullptr; *xx = nullptr; *Cpad = 0;
+    if (d.knn_workspace) {
+        SVNET_REQUIRE(d.knn_workspace_bytes >= svnet_knn_workspace_bytes(d.P / d.N, d.N, d.Os + 3 * d.Ov), SVNET_E_WORKSPACE,
+                      "%s: k-NN workspace too small", who);
+        apply_knn_supported(d.P, d.N, d.Os, d.Ov, Cpad);
+        *xT = (float*)d.knn_workspace;
+        *xx = *xT + d.P * ((d.Os + 3 * d.Ov + 7) / 8 * 8);
+    }
+    *lds = (size_t)((4 * d.Os + 4 * d.Ov + 3) & ~(int64_t)3) * sizeof(float) + apply_knn_lds_bytes(d.Os, d.Ov);
+    return SVNET_OK;
+}
+
+extern "C" int svnet_edgeblock_tail_f32(const svnet_block_tail_desc* desc, void* stream) {
+    SVNET_REQUIRE(desc, SVNET_E_ARG, "svnet_edgeblock_tail_f32: null descriptor");
+    const svnet_block_tail_desc& d = *desc;
+    SVNET_REQUIRE(d.scale1, SVNET_E_ARG, "svnet_edgeblock_tail_f32: scale1 is required");
+    size_t lds; float* xT; float* xx; int64_t Cpad;
+    const int rc = block_tail_check(d, "svnet_edgeblock_tail_f32", &lds, &xT, &xx, &Cpad);
+    if (rc != SVNET_OK) return rc;
+    const EdgeCoefArgs ca = {reinterpret_cast<const long long*>(d.stat1), d.stat_v, d.E, (int)d.Os, (int)d.Ov, d.scale1, d.gamma1, d.beta1,
+                             d.running_mean1, d.running_var1, d.gamma2, d.beta2, d.running_mean2, d.running_var2, d.training, d.eps, d.momentum};
+    hipLaunchKernelGGL(edgeblock_tail_kernel, dim3((unsigned)(d.P / APPLY_KNN_TP)), dim3(256), lds, (hipStream_t)stream, ca, d.coef,
+                       reinterpret_cast<long long*>(d.num_batches_tracked1), reinterpret_cast<long long*>(d.num_batches_tracked2), d.gate,
+                       (const int32_t*)d.hi, (const int32_t*)d.lo, d.mv, d.mvn, d.P, d.N, d.slope, d.s_out, d.v_out, d.s_cat, d.s_ld, d.v_cat,
+                       d.v_ld, xT, xx, Cpad);
+    SVNET_CHECK_LAUNCH("edgeblock_tail_kernel");
     return SVNET_OK;
 }

@@ -262,47 +262,56 @@ __global__ __launch_bounds__(256) void xyzblock_fwd_kernel(XyzFwdArgs fa) {
 }
 
 // coef = [A1 | B1 | mean_y | invstd_y (Os each) | Av | Bv | mean_n' | invstd_n' (Ov each)]  (same layout as edgeblock)
-__global__ void xyzblock_coeffs_kernel(const double* __restrict__ stat_y, const double* __restrict__ stat_v, int64_t E, int Os, int Ov,
-                                       const float* __restrict__ g1, const float* __restrict__ b1, float* __restrict__ rm1,
-                                       float* __restrict__ rv1, const float* __restrict__ g2, const float* __restrict__ b2,
-                                       float* __restrict__ rm2, float* __restrict__ rv2, int training, float eps, float momentum,
-                                       float* __restrict__ coef, long long* __restrict__ nbt1, long long* __restrict__ nbt2,
-                                       svnet_gate_fwd_job job, int coef_blocks) {
-    if ((int)blockIdx.x >= coef_blocks) { svnet_gate_fwd_block(job, (int)blockIdx.x - coef_blocks); return; }   // the gate MLP beside the coefficients
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && training) {
-        if (nbt1) *nbt1 += 1;
-        if (nbt2) *nbt2 += 1;
-    }
+struct XyzCoefArgs {
+    const double* stat_y; const double* stat_v; int64_t E; int Os, Ov;
+    const float* g1; const float* b1; float* rm1; float* rv1; const float* g2; const float* b2; float* rm2; float* rv2;
+    int training; float eps, momentum;
+};
+// channel c of both coefficient sets into `out` (global memory or a workgroup's LDS copy); commit: this caller also updates the running
+// statistics.  One body for the coefficient kernel and the tail kernel.
+__device__ __forceinline__ void xyz_coefs_channel(const XyzCoefArgs& a, int c, bool commit, float* coef) {
+    const int Os = a.Os, Ov = a.Ov;
+    const int64_t E = a.E;
     for (int part = 0; part < 2; ++part) {
         const int C = part == 0 ? Os : Ov;
         if (c >= C) continue;
-        const double* st = part == 0 ? stat_y : stat_v;
-        const float* g = part == 0 ? g1 : g2;
-        const float* bb = part == 0 ? b1 : b2;
-        float* rm = part == 0 ? rm1 : rm2;
-        float* rv = part == 0 ? rv1 : rv2;
+        const double* st = part == 0 ? a.stat_y : a.stat_v;
+        const float* g = part == 0 ? a.g1 : a.g2;
+        const float* bb = part == 0 ? a.b1 : a.b2;
+        float* rm = part == 0 ? a.rm1 : a.rm2;
+        float* rv = part == 0 ? a.rv1 : a.rv2;
         float* out = part == 0 ? coef : coef + 4 * Os;
         float mean, invstd;
-        if (training) {
+        if (a.training) {
             double s1 = 0.0, s2 = 0.0;                      // the forward kernel's slices, added in a fixed order
             for (int sl = 0; sl < SVNET_RED_SLICES; ++sl) { s1 += st[sl * 2 * C + c]; s2 += st[sl * 2 * C + C + c]; }
             const double m = s1 / (double)E;
             double var = s2 / (double)E - m * m;
             if (var < 0.0) var = 0.0;
             mean = (float)m;
-            invstd = (float)(1.0 / sqrt(var + (double)eps));
-            if (rm) rm[c] = (1.f - momentum) * rm[c] + momentum * mean;
-            if (rv) rv[c] = (1.f - momentum) * rv[c] + momentum * (float)(E > 1 ? var * ((double)E / (double)(E - 1)) : var);
+            invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+            if (commit && rm) rm[c] = (1.f - a.momentum) * rm[c] + a.momentum * mean;
+            if (commit && rv) rv[c] = (1.f - a.momentum) * rv[c] + a.momentum * (float)(E > 1 ? var * ((double)E / (double)(E - 1)) : var);
         } else {
             mean = rm[c];
-            invstd = 1.f / sqrtf(rv[c] + eps);
+            invstd = 1.f / sqrtf(rv[c] + a.eps);
         }
         out[c] = g[c] * invstd;
         out[C + c] = bb[c] - g[c] * mean * invstd;
         out[2 * C + c] = mean;
         out[3 * C + c] = invstd;
     }
+}
+
+__global__ void xyzblock_coeffs_kernel(XyzCoefArgs a, float* __restrict__ coef, long long* __restrict__ nbt1, long long* __restrict__ nbt2,
+                                       svnet_gate_fwd_job job, int coef_blocks) {
+    if ((int)blockIdx.x >= coef_blocks) { svnet_gate_fwd_block(job, (int)blockIdx.x - coef_blocks); return; }   // the gate MLP beside the coefficients
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && a.training) {
+        if (nbt1) *nbt1 += 1;
+        if (nbt2) *nbt2 += 1;
+    }
+    xyz_coefs_channel(a, c, true, coef);
 }
 
 // (one functor for both apply kernels below: bit-identical outputs)
@@ -365,6 +374,32 @@ __global__ __launch_bounds__(256) void xyzblock_apply_knn_kernel(const float* __
     extern __shared__ float apply_knn_rows[];
     const XyzApplyMath m = {y_max, y_min, mv, mvn, coef, coef + Os, coef + 4 * Os, coef + 4 * Os + Ov, gate, Os, Ov, slope};
     apply_knn_tiles<APPLY_KNN_TP>(m, P, N, Os, Ov, s_out, v_out, s_cat, s_ld, v_cat, v_ld, xT, xx, Cpad, apply_knn_rows);
+}
+
+// ---- coefficients + gate MLP + apply (+ the next k-NN's table) in one launch: as edgeblock_tail_kernel (edgeblock.hip)
+__global__ __launch_bounds__(256) void xyzblock_tail_kernel(XyzCoefArgs ca, float* __restrict__ coef, long long* __restrict__ nbt1,
+                                                            long long* __restrict__ nbt2, svnet_gate_fwd_job job,
+                                                            const float* __restrict__ y_max, const float* __restrict__ y_min,
+                                                            const float* __restrict__ mv, const float* __restrict__ mvn, int64_t P, int64_t N,
+                                                            float slope, float* __restrict__ s_out, float* __restrict__ v_out,
+                                                            float* __restrict__ s_cat, int64_t s_ld, float* __restrict__ v_cat, int64_t v_ld,
+                                                            float* __restrict__ xT, float* __restrict__ xx, int64_t Cpad) {
+    extern __shared__ float tail_lds[];                                  // [coef: 4 Os + 4 Ov (rounded to 4) | the tile's rows]
+    const int Os = ca.Os, Ov = ca.Ov;
+    const int ncoef = (4 * Os + 4 * Ov + 3) & ~3;
+    const bool first = blockIdx.x == 0;
+    const int64_t b = ((int64_t)blockIdx.x * APPLY_KNN_TP) / N;
+    if (first && threadIdx.x == 0 && ca.training) {
+        if (nbt1) *nbt1 += 1;
+        if (nbt2) *nbt2 += 1;
+    }
+    xyz_coefs_channel(ca, (int)threadIdx.x, first, tail_lds);
+    svnet_gate_fwd_block(job, (int)b);
+    __syncthreads();                                                     // the coefficients in LDS, the cloud's gate in global memory
+    if (first)
+        for (int i = threadIdx.x; i < 4 * Os + 4 * Ov; i += blockDim.x) coef[i] = tail_lds[i];
+    const XyzApplyMath m = {y_max, y_min, mv, mvn, tail_lds, tail_lds + Os, tail_lds + 4 * Os, tail_lds + 4 * Os + Ov, job.gate, Os, Ov, slope};
+    apply_knn_tiles<APPLY_KNN_TP>(m, P, N, Os, Ov, s_out, v_out, s_cat, s_ld, v_cat, v_ld, xT, xx, Cpad, tail_lds + ncoef);
 }
 
 // ---------------------------------------------------------------------------------------------- backward
@@ -653,10 +688,10 @@ extern "C" int svnet_xyzblock_coeffs_f32(const double* stat_y, const double* sta
     SVNET_REQUIRE(!gate_job || svnet_gate_fwd_job_ok(gate_job), SVNET_E_ARG, "svnet_xyzblock_coeffs_f32: bad gate job");
     const int coef_blocks = (int)svnet_cdiv(n, 256);
     const svnet_gate_fwd_job job = gate_job ? *gate_job : svnet_gate_fwd_job{};
-    hipLaunchKernelGGL(xyzblock_coeffs_kernel, dim3((unsigned)(coef_blocks + (gate_job ? gate_job->B : 0))), dim3(256), 0, (hipStream_t)stream, stat_y, stat_v, E,
-                       (int)Os, (int)Ov, gamma1, beta1, running_mean1, running_var1, gamma2, beta2, running_mean2, running_var2,
-                       training, eps, momentum, coef, reinterpret_cast<long long*>(num_batches_tracked1),
-                       reinterpret_cast<long long*>(num_batches_tracked2), job, coef_blocks);
+    const XyzCoefArgs ca = {stat_y, stat_v, E, (int)Os, (int)Ov, gamma1, beta1, running_mean1, running_var1, gamma2, beta2, running_mean2,
+                            running_var2, training, eps, momentum};
+    hipLaunchKernelGGL(xyzblock_coeffs_kernel, dim3((unsigned)(coef_blocks + (gate_job ? gate_job->B : 0))), dim3(256), 0, (hipStream_t)stream, ca,
+                       coef, reinterpret_cast<long long*>(num_batches_tracked1), reinterpret_cast<long long*>(num_batches_tracked2), job, coef_blocks);
     SVNET_CHECK_LAUNCH("xyzblock_coeffs_kernel");
     return SVNET_OK;
 }
@@ -691,6 +726,38 @@ extern "C" int svnet_xyzblock_apply_knn_f32(const float* y_max, const float* y_m
     hipLaunchKernelGGL(xyzblock_apply_knn_kernel, dim3((unsigned)(P / APPLY_KNN_TP)), dim3(256), apply_knn_lds_bytes(Os, Ov), (hipStream_t)stream,
                        y_max, y_min, mv, mvn, coef, gate, P, N, (int)Os, (int)Ov, slope, s_out, v_out, s_cat, s_ld, v_cat, v_ld, xT, xx, Cpad);
     SVNET_CHECK_LAUNCH("xyzblock_apply_knn_kernel");
+    return SVNET_OK;
+}
+
+extern "C" int svnet_xyzblock_tail_f32(const svnet_block_tail_desc* desc, void* stream) {
+    SVNET_REQUIRE(desc, SVNET_E_ARG, "svnet_xyzblock_tail_f32: null descriptor");
+    const svnet_block_tail_desc& d = *desc;
+    const char* who = "svnet_xyzblock_tail_f32";
+    SVNET_REQUIRE(d.hi && d.lo && d.mv && d.mvn && d.coef && d.s_out && d.v_out && d.gamma1 && d.beta1 && d.gamma2 && d.beta2, SVNET_E_ARG,
+                  "%s: null pointer", who);
+    SVNET_REQUIRE(d.training ? (d.stat1 && d.stat_v) : (d.running_mean1 && d.running_var1 && d.running_mean2 && d.running_var2), SVNET_E_ARG,
+                  "%s: missing statistics", who);
+    SVNET_REQUIRE(svnet_gate_fwd_job_ok(&d.gate) && d.gate.Ov == d.Ov && d.gate.B * d.N == d.P, SVNET_E_ARG, "%s: bad gate job", who);
+    SVNET_REQUIRE((!d.s_cat || d.s_ld >= d.Os) && (!d.v_cat || d.v_ld >= d.Ov), SVNET_E_ARG, "%s: concatenation row shorter than the slice", who);
+    SVNET_REQUIRE(svnet_block_tail_supported(d.P, d.N, d.Os, d.Ov, d.knn_workspace != nullptr), SVNET_E_UNSUPPORTED,
+                  "%s: P=%lld N=%lld Os=%lld Ov=%lld not supported (svnet_block_tail_supported)", who, (long long)d.P, (long long)d.N,
+                  (long long)d.Os, (long long)d.Ov);
+    float* xT = nullptr; float* xx = nullptr; int64_t Cpad = 0;
+    if (d.knn_workspace) {
+        SVNET_REQUIRE(d.knn_workspace_bytes >= svnet_knn_workspace_bytes(d.P / d.N, d.N, d.Os + 3 * d.Ov), SVNET_E_WORKSPACE,
+                      "%s: k-NN workspace too small", who);
+        apply_knn_supported(d.P, d.N, d.Os, d.Ov, &Cpad);
+        xT = (float*)d.knn_workspace;
+        xx = xT + d.P * ((d.Os + 3 * d.Ov + 7) / 8 * 8);
+    }
+    const size_t lds = (size_t)((4 * d.Os + 4 * d.Ov + 3) & ~(int64_t)3) * sizeof(float) + apply_knn_lds_bytes(d.Os, d.Ov);
+    const XyzCoefArgs ca = {reinterpret_cast<const double*>(d.stat1), d.stat_v, d.E, (int)d.Os, (int)d.Ov, d.gamma1, d.beta1, d.running_mean1,
+                            d.running_var1, d.gamma2, d.beta2, d.running_mean2, d.running_var2, d.training, d.eps, d.momentum};
+    hipLaunchKernelGGL(xyzblock_tail_kernel, dim3((unsigned)(d.P / APPLY_KNN_TP)), dim3(256), lds, (hipStream_t)stream, ca, d.coef,
+                       reinterpret_cast<long long*>(d.num_batches_tracked1), reinterpret_cast<long long*>(d.num_batches_tracked2), d.gate,
+                       (const float*)d.hi, (const float*)d.lo, d.mv, d.mvn, d.P, d.N, d.slope, d.s_out, d.v_out, d.s_cat, d.s_ld, d.v_cat,
+                       d.v_ld, xT, xx, Cpad);
+    SVNET_CHECK_LAUNCH("xyzblock_tail_kernel");
     return SVNET_OK;
 }
 

@@ -1,6 +1,7 @@
 """GPU tests (-m gpu) of the fused edge block (csrc/edgeblock.hip) against the layer-by-layer HIP path (tier 1,
 itself pinned to the oracle by test_hip_parity.py) and against the oracle, on identical inputs."""
 import contextlib
+import ctypes
 import io
 
 import numpy as np
@@ -545,6 +546,123 @@ def test_models_give_the_same_bits_with_and_without_the_table_ahead(model_name, 
     assert np.array_equal(res[True][0], res[False][0]) and res[True][1] == res[False][1]
     # (gradients: the backward never sees the table - the same kernels on the same bits, but their float atomics arrive in another order
     #  from run to run, and cancelling sums such as a binarized layer's scale gradient show that at 1e-2 of their own size)
+    gmax = max(float(np.abs(g_).max()) for g_ in res[False][2].values())
+    for n, g_ in res[True][2].items():
+        ref = res[False][2][n]
+        assert float(np.abs(g_ - ref).max()) <= 1e-4 * float(np.abs(ref).max()) + 1e-5 * gmax, n
+
+
+# ----------------------------------------------------------------------------- coefficients + gate MLP + apply (+ table) as one launch
+
+@pytest.mark.parametrize("table", [True, False], ids=["with_table", "no_table"])
+@pytest.mark.parametrize("training", [True, False], ids=["train", "eval"])
+@pytest.mark.parametrize("xyz", [False, True], ids=["edge_level", "first_level"])
+@pytest.mark.parametrize("cfg", [(2, 1024, 32, 10, 64), (1, 1024, 128, 42, 128), (2, 2048, 64, 24, 64), (3, 96, 32, 10, 6)],
+                         ids=["conv2", "conv4", "pseg3", "n96"])
+def test_block_tail_is_bit_identical_to_its_three_launches(cfg, xyz, training, table, hip_device):
+    """svnet_{edgeblock,xyzblock}_tail_f32 against svnet_*_coeffs_f32 (gate MLP inside) + svnet_*_apply[_knn]_f32: coefficients, running
+    statistics, counters, the gate MLP's three outputs, the pooled features, their concatenation slices and the k-NN workspace, bit for
+    bit, in train and eval mode (sv_layers.py:172-196: bn1 / bn2 / gate of an SVBlock behind the fused edge pass)."""
+    from svnet_amd import _lib
+    from svnet_amd._ops import _p, _stream, call, BN_EPS, BN_MOMENTUM, RED_SLICES
+    B, N, Os, Ov, Cin = cfg
+    P, E, k, H = B * N, B * N * 20, 20, max(Ov // 2, 1)
+    L = _lib.lib()
+    assert L.svnet_block_tail_supported(P, N, Os, Ov, int(table)) == 1
+    g = torch.Generator().manual_seed(11 + Os + N)
+    dev = hip_device
+    f32 = dict(dtype=torch.float32, device=dev)
+    if xyz:
+        hi = torch.randn(P, Os, generator=g).to(dev)
+        lo = (hi.cpu() - torch.rand(P, Os, generator=g)).to(dev)
+        mean, var = torch.randn(Os, generator=g).double(), torch.rand(Os, generator=g).double() + 0.1
+        per = torch.stack([mean * E / RED_SLICES, (var + mean * mean) * E / RED_SLICES])           # [2, Os]
+        stat1 = (per.unsqueeze(0) * (1.0 + 0.01 * torch.randn(RED_SLICES, 2, Os, generator=g).double())).reshape(-1).to(dev)
+        sc1 = None
+    else:
+        hi = torch.randint(-200, 200, (P, Os), generator=g, dtype=torch.int32).to(dev)
+        lo = (hi.cpu() - torch.randint(0, 50, (P, Os), generator=g, dtype=torch.int32)).to(dev)
+        mean, var = torch.randn(Os, generator=g).double() * 3, torch.rand(Os, generator=g).double() * 30 + 1
+        per = torch.stack([mean * E / RED_SLICES, (var + mean * mean) * E / RED_SLICES])
+        stat1 = (per.unsqueeze(0) * (1.0 + 0.01 * torch.rand(RED_SLICES, 2, Os, generator=g).double())).round().long().reshape(-1).to(dev)
+        sc1 = (torch.rand(Os, generator=g) * 0.1 + 0.01).to(dev)
+    mv_m, mv_v = torch.rand(Ov, generator=g).double() + 0.5, torch.rand(Ov, generator=g).double() * 0.2 + 0.01
+    per_v = torch.stack([mv_m * E / RED_SLICES, (mv_v + mv_m * mv_m) * E / RED_SLICES])
+    stat_v = (per_v.unsqueeze(0) * (1.0 + 0.01 * torch.rand(RED_SLICES, 2, Ov, generator=g).double())).reshape(-1).to(dev)
+    mv, mvn = torch.randn(P, 3, Ov, generator=g).to(dev), torch.randn(P, 3, Ov, generator=g).to(dev)
+    g1, b1 = (torch.randn(Os, generator=g)).to(dev), torch.randn(Os, generator=g).to(dev)          # both signs of gamma
+    g2, b2 = (torch.rand(Ov, generator=g) + 0.5).to(dev), torch.randn(Ov, generator=g).to(dev)
+    gate_sum = (torch.randn(B, Cin, generator=g).double() * N * k).to(dev)
+    W0, W2 = (torch.randn(H, Cin, generator=g) * 0.3).to(dev), torch.randn(Ov, H, generator=g).to(dev)
+    nbytes = L.svnet_knn_workspace_bytes(B, N, Os + 3 * Ov)
+    name = "xyzblock" if xyz else "edgeblock"
+    out = {}
+    for fused in (False, True):
+        rm1, rv1 = torch.linspace(-1, 1, Os).to(dev), torch.linspace(0.5, 2, Os).to(dev)
+        rm2, rv2 = torch.linspace(0.2, 1, Ov).to(dev), torch.linspace(0.5, 2, Ov).to(dev)
+        nbt1, nbt2 = torch.full((), 3, dtype=torch.int64, device=dev), torch.full((), 5, dtype=torch.int64, device=dev)
+        coef = torch.empty(4 * Os + 4 * Ov, **f32)
+        h, gate, gin = torch.empty(B, H, **f32), torch.empty(B, Ov, **f32), torch.empty(B, Cin, **f32)
+        s_out, v_out = torch.empty(B, N, Os, **f32), torch.empty(B, N, 3, Ov, **f32)
+        s_cat, v_cat = torch.zeros(P, Os + 7, **f32), torch.zeros(P, 3, Ov + 5, **f32)
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        job = _lib.GateFwdJob(None, _p(gate_sum), _p(gin), 1.0 / float(N * k), _p(W0), _p(W2), B, Cin, H, Ov, _p(h), _p(gate))
+        st1, stv = (stat1, stat_v) if training else (None, None)
+        if fused:
+            d = _lib.BlockTailDesc()
+            d.stat1, d.stat_v, d.E, d.Os, d.Ov, d.scale1 = _p(st1), _p(stv), E, Os, Ov, _p(sc1)
+            d.gamma1, d.beta1, d.running_mean1, d.running_var1 = _p(g1), _p(b1), _p(rm1), _p(rv1)
+            d.gamma2, d.beta2, d.running_mean2, d.running_var2 = _p(g2), _p(b2), _p(rm2), _p(rv2)
+            d.training, d.eps, d.momentum = int(training), BN_EPS, BN_MOMENTUM
+            d.coef, d.num_batches_tracked1, d.num_batches_tracked2 = _p(coef), _p(nbt1), _p(nbt2)
+            d.gate = job
+            d.hi, d.lo, d.mv, d.mvn, d.P, d.N, d.slope = _p(hi), _p(lo), _p(mv), _p(mvn), P, N, 0.2
+            d.s_out, d.v_out, d.s_cat, d.s_ld, d.v_cat, d.v_ld = _p(s_out), _p(v_out), _p(s_cat[:, 3:]), Os + 7, _p(v_cat[:, :, 2:]), Ov + 5
+            if table:
+                d.knn_workspace, d.knn_workspace_bytes = _p(ws), nbytes
+            call("svnet_%s_tail_f32" % name, ctypes.byref(d), _stream())
+        else:
+            stats = (_p(st1), _p(stv), E, Os, Ov) + ((_p(sc1),) if not xyz else ())
+            call("svnet_%s_coeffs_f32" % name, *stats, _p(g1), _p(b1), _p(rm1), _p(rv1), _p(g2), _p(b2), _p(rm2), _p(rv2), int(training), BN_EPS,
+                 BN_MOMENTUM, _p(coef), _p(nbt1), _p(nbt2), ctypes.byref(job), _stream())
+            args = (_p(hi), _p(lo), _p(mv), _p(mvn), _p(coef), _p(gate), P, N, Os, Ov, 0.2, _p(s_out), _p(v_out), _p(s_cat[:, 3:]), Os + 7,
+                    _p(v_cat[:, :, 2:]), Ov + 5)
+            if table:
+                call("svnet_%s_apply_knn_f32" % name, *args, _p(ws), nbytes, _stream())
+            else:
+                call("svnet_%s_apply_f32" % name, *args, _stream())
+        torch.cuda.synchronize()
+        out[fused] = dict(coef=coef, h=h, gate=gate, gin=gin, s_out=s_out, v_out=v_out, s_cat=s_cat, v_cat=v_cat, ws=ws, rm1=rm1, rv1=rv1, rm2=rm2,
+                          rv2=rv2, nbt1=nbt1, nbt2=nbt2)
+        out[fused] = {n: t.cpu() for n, t in out[fused].items()}
+    for n, t in out[True].items():
+        assert torch.equal(t, out[False][n]), n
+    assert int(out[True]["nbt1"]) == (4 if training else 3) and int(out[True]["nbt2"]) == (6 if training else 5)
+    assert torch.isfinite(out[True]["s_out"]).all() and torch.isfinite(out[True]["v_out"]).all()
+    if training:
+        assert not torch.equal(out[True]["rm1"], torch.linspace(-1, 1, Os))            # the running statistics moved - once
+
+
+@pytest.mark.parametrize("model_name,B,N,k", [("sv_dgcnn_cls", 2, 128, 8), ("sv_dgcnn_pseg", 2, 64, 6)])
+def test_models_give_the_same_bits_with_and_without_the_block_tail(model_name, B, N, k, hip_device, monkeypatch):
+    """The callers with config.FUSE_BLOCK_TAIL on and off: logits, loss and BatchNorm buffers identical, gradients to their atomics' noise."""
+    from svnet_amd import config
+    from oracle import params as oparams
+    from tests.test_hip_train_parity import build_model, hip_step
+    x, l, y = C.model_inputs("tail_" + model_name, model_name, B, N)
+    state = oparams.synthetic_params(model_name, binary=True, seed=C.SEED)
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(config, "FUSE_BLOCK_TAIL", on)
+        m = build_model(model_name, True, k, hip_device, state).train()
+        logits, loss, got, _ = hip_step(m, x, l, y, hip_device)
+        torch.cuda.synchronize()
+        res[on] = (logits, loss, got, {n: t.cpu() for n, t in m.state_dict().items() if "running_" in n or "num_batches" in n})
+        with torch.no_grad():
+            res[on] += (m.eval()(*((x.to(hip_device),) if l is None else (x.to(hip_device), l.to(hip_device)))).cpu(),)
+    assert np.array_equal(res[True][0], res[False][0]) and res[True][1] == res[False][1] and torch.equal(res[True][4], res[False][4])
+    for n, t in res[True][3].items():
+        assert torch.equal(t, res[False][3][n]), n
     gmax = max(float(np.abs(g_).max()) for g_ in res[False][2].values())
     for n, g_ in res[True][2].items():
         ref = res[False][2][n]
