@@ -47,7 +47,7 @@ int svnet_slices_sum_f64(double* buf, int64_t L, void* stream);
  * changes its required length (200: sliced accumulators, SVNET_SLICED_LEN; 400: this header; 401: the totals of a sliced accumulator are
  * written by its consumer, svnet_slices_sum_*; 402: GX of svnet_v2s_bwd_*, gw of svnet_xyzblock_bwd_f32 and col_sum of svnet_gemm_f32 are sliced accumulators; 403: svnet_binweight_grad_f32 takes sliced inputs).  svnet_version() returns the value the
  * library was BUILT with: a caller compiled against another header must refuse to run (svnet_amd/_lib.py does).                   */
-#define SVNET_ABI_VERSION 416
+#define SVNET_ABI_VERSION 417
 int svnet_version(void);
 const char* svnet_last_error(void);
 
@@ -436,6 +436,13 @@ int svnet_v2s_bwd_f32(const float* v, const float* w_eff, const float* ds, const
  * of a wider gradient (rows of stride ds_ld).                                                                                       */
 int svnet_v2s_cat_fwd_f32(const float* v, const float* w_eff, const float* pre, int64_t pre_cols, int64_t M, int64_t C, int64_t J,
                           float* out, int64_t out_ld, void* stream);
+/* ... and, from the copy of `pre` it makes anyway, the per-cloud column sums of pre: pre_sum [M / rows_per_cloud, pre_cols] fp64 (caller
+ * zero-fills) - the input of the SVBlock's gate MLP (sv_layers.py:179: s.mean over the points; svnet_gate_mlp_fwd_f32 with gin_f64 =
+ * pre_sum, in_scale = 1 / rows_per_cloud), so that no pooling pass reads s a second time.  svnet_v2s_cat_sum_supported: 24 < C <= 192,
+ * pre_cols <= 256 (C <= 96) / 512, whole clouds, rows_per_cloud a multiple of 32 (C <= 96) / 16.                                      */
+int svnet_v2s_cat_sum_supported(int64_t M, int64_t C, int64_t pre_cols, int64_t rows_per_cloud);
+int svnet_v2s_cat_sum_fwd_f32(const float* v, const float* w_eff, const float* pre, int64_t pre_cols, int64_t M, int64_t C, int64_t multi,
+                              float* out, int64_t out_ld, double* pre_sum, int64_t rows_per_cloud, void* stream);
 int svnet_v2s_bwd_ld_f32(const float* v, const float* w_eff, const float* ds, int64_t ds_ld, const float* dz_in, int64_t M, int64_t C,
                          int64_t J, float* dv, float* GX, void* stream);
 /* Frame projection with a GIVEN per-row frame z [M,3,J] (the back-projection einsum 'bimj,bijk->bimk' of

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVNET_DIAG_LIB") or os.path.join(_HERE, "libsvnet_hip.so")    # (SVNET_DIAG_LIB: an ablation build, tools/ only)
 _lib = None
-ABI_VERSION = 416       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
+ABI_VERSION = 417       # include/svnet_hip.h SVNET_ABI_VERSION: argument lists / buffer-length contracts this binding was written against
 
 c_p = ctypes.c_void_p
 c_i64 = ctypes.c_int64
@@ -197,6 +197,8 @@ SIGNATURES = {
     "svnet_v2s_fwd_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "svnet_v2s_bwd_f32": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "svnet_v2s_cat_fwd_f32": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_i64, c_p]),
+    "svnet_v2s_cat_sum_supported": (c_int, [c_i64, c_i64, c_i64, c_i64]),
+    "svnet_v2s_cat_sum_fwd_f32": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p]),
     "svnet_v2s_bwd_ld_f32": (c_int, [c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "svnet_vproject_fwd_f32": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p]),
     "svnet_vproject_bwd_f32": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),

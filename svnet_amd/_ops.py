@@ -1008,10 +1008,12 @@ class V2SCat(torch.autograd.Function):
     the gradient on as a view and reads the Vector2Scalar part where it lies (svnet_v2s_bwd_ld_f32)."""
 
     @staticmethod
-    def forward(ctx, s, v, W, scale, training=True, clouds=0):
+    def forward(ctx, s, v, W, scale, training=True, clouds=0, gate_W0=None, gate_W2=None):
         """clouds > 0: also returns mean(s) over each cloud's rows [clouds, Cs] (the gate's input, sv_layers.py:179): s then has ONE
         consumer in the autograd graph, and the backward writes its gradient once - the cat gradient's s columns plus the mean's
-        broadcast - instead of a broadcast pass and a strided add of two gradients in front of the layer's backward."""
+        broadcast - instead of a broadcast pass and a strided add of two gradients in front of the layer's backward.
+        With gate_W0 / gate_W2 (the block's gate MLP, sv_layers.py:156-161): returns (cat, gate) - the column sums of s come out of the
+        concatenation kernel's own copy of s (fp64, svnet_v2s_cat_sum_fwd_f32) and the MLP starts from them: no pooling pass over s."""
         _hip(s, v, W, scale)
         ctx.training = bool(training)
         v3 = _f32c(v).reshape(-1, 3, v.shape[-1])
@@ -1026,20 +1028,61 @@ class V2SCat(torch.autograd.Function):
         else:
             sc, w_eff = None, W
         out = torch.empty((M, Cs + C * J), dtype=torch.float32, device=v.device)
-        call("svnet_v2s_cat_fwd_f32", _p(v3), _p(w_eff), _p(s2), Cs, M, C, J, _p(out), Cs + C * J, _stream())
-        ctx.save_for_backward(v3, W, w_eff, sc)
         ctx.meta = (M, C, J, Cs, s.shape, v.shape, None if scale is None else scale.shape)
         ctx.clouds = int(clouds)
         ctx.set_materialize_grads(False)
         cat = out.view(s.shape[:-1] + (Cs + C * J,))
+        ctx.with_gate = False
+        if clouds and gate_W0 is not None and _lib.lib().svnet_v2s_cat_sum_supported(M, C, Cs, M // clouds):
+            rows = M // clouds
+            s_sum = _zeros((clouds, Cs), torch.float64, v.device)
+            call("svnet_v2s_cat_sum_fwd_f32", _p(v3), _p(w_eff), _p(s2), Cs, M, C, J, _p(out), Cs + C * J, _p(s_sum), rows, _stream())
+            W0c, W2c = _f32c(gate_W0), _f32c(gate_W2)
+            H, Ov = W0c.shape[0], W2c.shape[0]
+            pooled = torch.empty((clouds, Cs), dtype=torch.float32, device=v.device)        # = float(s_sum): the MLP scales it by 1 / rows
+            h = torch.empty((clouds, H), dtype=torch.float32, device=v.device)
+            gate = torch.empty((clouds, Ov), dtype=torch.float32, device=v.device)
+            call("svnet_gate_mlp_fwd_f32", None, _p(s_sum), _p(pooled), 1.0 / float(rows), _p(W0c), _p(W2c), clouds, Cs, H, Ov, _p(h), _p(gate),
+                 None, 0, _stream())
+            _tap_act(gate_W0, 2, h)
+            ctx.save_for_backward(v3, W, w_eff, sc, pooled, W0c, W2c, h, gate)
+            ctx.with_gate = True
+            ctx.gate_in_scale = 1.0 / float(rows)
+            return cat, gate
+        call("svnet_v2s_cat_fwd_f32", _p(v3), _p(w_eff), _p(s2), Cs, M, C, J, _p(out), Cs + C * J, _stream())
+        ctx.save_for_backward(v3, W, w_eff, sc)
         if clouds:
             s_mean, _ = pool_raw(s2, clouds, M // clouds, Cs, 1)
+            if gate_W0 is not None:                          # (shape outside the summing kernel's: the mean by its own pass, the MLP here)
+                W0c, W2c = _f32c(gate_W0), _f32c(gate_W2)
+                H, Ov = W0c.shape[0], W2c.shape[0]
+                h = torch.empty((clouds, H), dtype=torch.float32, device=v.device)
+                gate = torch.empty((clouds, Ov), dtype=torch.float32, device=v.device)
+                call("svnet_gate_mlp_fwd_f32", _p(s_mean), None, None, 1.0, _p(W0c), _p(W2c), clouds, Cs, H, Ov, _p(h), _p(gate), None, 0, _stream())
+                _tap_act(gate_W0, 2, h)
+                ctx.save_for_backward(v3, W, w_eff, sc, s_mean, W0c, W2c, h, gate)
+                ctx.with_gate = True
+                ctx.gate_in_scale = 1.0
+                return cat, gate
             return cat, s_mean
         return cat
 
     @staticmethod
     def backward(ctx, g, g_mean=None):
-        v3, W, w_eff, sc = ctx.saved_tensors
+        dW0 = dW2 = None
+        if ctx.with_gate:        # the second output was the gate: its MLP's backward first - g_mean becomes dL/d(mean of s)
+            v3, W, w_eff, sc, pooled, W0g, W2g, hg, gateg = ctx.saved_tensors
+            if g_mean is not None:
+                Bc, Cin = pooled.shape
+                H, Ov = W0g.shape[0], W2g.shape[0]
+                zb = _zeros((H * Cin + Ov * H,), torch.float32, pooled.device)
+                dW0, dW2 = zb[:H * Cin].view(H, Cin), zb[H * Cin:].view(Ov, H)
+                dmean = torch.empty_like(pooled)
+                call("svnet_gate_mlp_bwd_f32", _p(_f32c(g_mean)), _p(gateg), _p(hg), _p(pooled), ctx.gate_in_scale, _p(W0g), _p(W2g), Bc, Cin, H, Ov,
+                     1.0, _p(dmean), _p(dW0), _p(dW2), _stream())
+                g_mean = dmean
+        else:
+            v3, W, w_eff, sc = ctx.saved_tensors
         M, C, J, Cs, sshape, vshape, scshape = ctx.meta
         if g is None:                                   # (only the mean was used)
             g = torch.zeros((M, Cs + C * J), dtype=torch.float32, device=v3.device)
@@ -1062,7 +1105,7 @@ class V2SCat(torch.autograd.Function):
         else:
             call("svnet_slices_sum_f32", _p(gxb), J * C, _stream())
             dW, dsc = gxb[:J * C].view(J, C), None
-        return ds, dv.view(vshape), dW, dsc, None, None
+        return ds, dv.view(vshape), dW, dsc, None, None, dW0, dW2
 
 
 class VProject(torch.autograd.Function):

@@ -89,3 +89,5 @@ EDGE_DENSE_WEIGHTS = True
 KNN_TABLE_AHEAD = True
 # ... and the coefficients + gate MLP + apply pass of a fused level are ONE launch (svnet_*_tail_f32) instead of two on the critical path
 FUSE_BLOCK_TAIL = True
+# conv5's concatenation kernel also sums the s columns it copies per cloud; the gate MLP starts from those sums (no pooling pass over s)
+FUSE_CAT_MEAN = True

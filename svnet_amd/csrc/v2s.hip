@@ -17,13 +17,22 @@ constexpr int J = 3;    // `multi` is 3 in every SV model
 template <int G>
 __device__ __forceinline__ float group_sum(float v) { return group_sum_dpp<G>(v); }   // (DPP / row swaps: no LDS crossbar)
 
-template <int G, int CPL>
+constexpr int V2S_SUM_ROWS = 4, V2S_SUM_COLS = 8;      // SUM mode: rows per group and workgroup, copied columns per lane (pre_cols <= 8 G)
+template <int G, int CPL, bool SUM = false>
 __global__ __launch_bounds__(256) void v2s_fwd_kernel(const float* __restrict__ v, const float* __restrict__ w, int64_t M, int C,
                                                       float* __restrict__ s, int64_t s_ld, float* __restrict__ z_out,
-                                                      const float* __restrict__ pre, int pre_cols) {
+                                                      const float* __restrict__ pre, int pre_cols, double* __restrict__ pre_sum = nullptr,
+                                                      int64_t rows_per_cloud = 0) {
+    // SUM (svnet_v2s_cat_sum_fwd_f32): also the per-cloud column sums of `pre` - the input of the SVBlock's gate MLP (sv_layers.py:179) -
+    // from the copy this kernel makes of it anyway.  A workgroup then owns V2S_SUM_ROWS consecutive rows per group (one cloud: checked on
+    // the host), a lane adds up the columns it copies, the groups meet in LDS and the workgroup adds ONE fp64 value per column.
+    constexpr int GPB = 256 / G;
     const int g = threadIdx.x % G;
-    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
-    const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) / G;
+    const int64_t group = SUM ? (int64_t)blockIdx.x * (GPB * V2S_SUM_ROWS) + threadIdx.x / G : ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t ngroups = SUM ? GPB : ((int64_t)gridDim.x * blockDim.x) / G;
+    float psum[SUM ? V2S_SUM_COLS : 1];
+#pragma unroll
+    for (int q = 0; q < (SUM ? V2S_SUM_COLS : 1); ++q) psum[q] = 0.f;
     float wr[J][CPL];
 #pragma unroll
     for (int t = 0; t < CPL; ++t) {
@@ -31,7 +40,7 @@ __global__ __launch_bounds__(256) void v2s_fwd_kernel(const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < J; ++j) wr[j][t] = (c < C) ? w[j * C + c] : 0.f;
     }
-    const int64_t iters = (M + ngroups - 1) / ngroups;  // uniform trip count: shuffles need every lane
+    const int64_t iters = SUM ? V2S_SUM_ROWS : (M + ngroups - 1) / ngroups;  // uniform trip count: shuffles need every lane
     for (int64_t it = 0; it < iters; ++it) {
         const int64_t m = group + it * ngroups;
         const bool live = m < M;
@@ -64,13 +73,33 @@ __global__ __launch_bounds__(256) void v2s_fwd_kernel(const float* __restrict__ 
                 }
             }
             // cat[pre, s] in place: the row's leading columns are copied by the same lanes (s points pre_cols floats into the row)
-            if (pre) for (int c = g; c < pre_cols; c += G) s[m * s_ld - pre_cols + c] = pre[m * pre_cols + c];
+            if (SUM) {
+#pragma unroll
+                for (int q = 0; q < V2S_SUM_COLS; ++q) {
+                    const int c = g + G * q;
+                    if (c < pre_cols) { const float t = pre[m * pre_cols + c]; s[m * s_ld - pre_cols + c] = t; psum[q] += t; }
+                }
+            } else if (pre) for (int c = g; c < pre_cols; c += G) s[m * s_ld - pre_cols + c] = pre[m * pre_cols + c];
             if (z_out && g == 0) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int j = 0; j < J; ++j) z_out[(m * 3 + i) * J + j] = z[i][j];
             }
+        }
+    }
+    if constexpr (SUM) {
+        __shared__ float part[GPB][G * V2S_SUM_COLS];
+        const int gi = threadIdx.x / G;
+#pragma unroll
+        for (int q = 0; q < V2S_SUM_COLS; ++q) part[gi][g + G * q] = psum[q];
+        __syncthreads();
+        const int64_t cloud = ((int64_t)blockIdx.x * (GPB * V2S_SUM_ROWS)) / rows_per_cloud;
+        for (int c = threadIdx.x; c < pre_cols; c += blockDim.x) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < GPB; ++q) t += part[q][c];
+            atomicAdd(&pre_sum[cloud * pre_cols + c], (double)t);
         }
     }
 }
@@ -244,7 +273,7 @@ inline unsigned v2s_grid(int64_t M, int G) {
 }  // namespace
 
 static int v2s_fwd_launch(const float* v, const float* w_eff, int64_t M, int64_t C, int64_t Jn, float* s, int64_t s_ld, float* z_out,
-                          const float* pre, int64_t pre_cols, void* stream) {
+                          const float* pre, int64_t pre_cols, void* stream, double* pre_sum = nullptr, int64_t rows_per_cloud = 0) {
     SVNET_REQUIRE(v && w_eff && s && M >= 0 && C > 0 && s_ld >= C * J + (pre ? pre_cols : 0) && (!pre || pre_cols > 0), SVNET_E_ARG,
                   "svnet_v2s_fwd_f32: bad arguments");
     SVNET_REQUIRE(Jn == J && C <= 768, SVNET_E_UNSUPPORTED, "svnet_v2s_fwd_f32: needs multi == 3 and C <= 768 (got %lld, %lld)",
@@ -252,6 +281,19 @@ static int v2s_fwd_launch(const float* v, const float* w_eff, int64_t M, int64_t
     if (M == 0) return SVNET_OK;
     hipStream_t st = (hipStream_t)stream;
 #define SVNET_V2S(G, CPL) hipLaunchKernelGGL((v2s_fwd_kernel<G, CPL>), dim3(v2s_grid(M, G)), dim3(256), 0, st, v, w_eff, M, (int)C, s, s_ld, z_out, pre, (int)pre_cols)
+    if (pre_sum) {
+        // (the widths the callers have: conv5 of the DGCNN callers, C = 83 / 80 with 256 leading columns)
+        const int G_ = C <= 96 ? 32 : 64;
+        SVNET_REQUIRE(C > 24 && C <= 192 && pre && pre_cols <= (int64_t)V2S_SUM_COLS * G_ && rows_per_cloud > 0 && M % rows_per_cloud == 0 &&
+                          rows_per_cloud % ((256 / G_) * V2S_SUM_ROWS) == 0, SVNET_E_UNSUPPORTED,
+                      "svnet_v2s_cat_sum_fwd_f32: C=%lld, pre_cols=%lld, rows_per_cloud=%lld not supported", (long long)C, (long long)pre_cols,
+                      (long long)rows_per_cloud);
+        const unsigned blocks = (unsigned)(M / ((256 / G_) * V2S_SUM_ROWS));
+        if (G_ == 32) hipLaunchKernelGGL((v2s_fwd_kernel<32, 3, true>), dim3(blocks), dim3(256), 0, st, v, w_eff, M, (int)C, s, s_ld, z_out, pre, (int)pre_cols, pre_sum, rows_per_cloud);
+        else hipLaunchKernelGGL((v2s_fwd_kernel<64, 3, true>), dim3(blocks), dim3(256), 0, st, v, w_eff, M, (int)C, s, s_ld, z_out, pre, (int)pre_cols, pre_sum, rows_per_cloud);
+        SVNET_CHECK_LAUNCH("v2s_fwd_kernel<sum>");
+        return SVNET_OK;
+    }
     if (C <= 3) SVNET_V2S(1, 3);
     else if (C <= 24) SVNET_V2S(8, 3);
     else if (C <= 96) SVNET_V2S(32, 3);
@@ -272,6 +314,19 @@ extern "C" int svnet_v2s_cat_fwd_f32(const float* v, const float* w_eff, const f
                                      int64_t Jn, float* out, int64_t out_ld, void* stream) {
     SVNET_REQUIRE(pre && out && pre_cols > 0, SVNET_E_ARG, "svnet_v2s_cat_fwd_f32: bad arguments");
     return v2s_fwd_launch(v, w_eff, M, C, Jn, out + pre_cols, out_ld, nullptr, pre, pre_cols, stream);
+}
+
+extern "C" int svnet_v2s_cat_sum_supported(int64_t M, int64_t C, int64_t pre_cols, int64_t rows_per_cloud) {
+    const int64_t G_ = C <= 96 ? 32 : 64;
+    return (C > 24 && C <= 192 && pre_cols > 0 && pre_cols <= (int64_t)V2S_SUM_COLS * G_ && rows_per_cloud > 0 && M > 0 && M % rows_per_cloud == 0 &&
+            rows_per_cloud % ((256 / G_) * V2S_SUM_ROWS) == 0) ? 1 : 0;
+}
+/* ... and pre_sum [M / rows_per_cloud, pre_cols] (fp64, caller zero-fills) += the column sums of pre over each cloud's rows: the gate MLP's
+ * input (svnet_gate_mlp_fwd_f32 with gin_f64 = pre_sum, in_scale = 1 / rows_per_cloud), from the copy of pre this kernel makes anyway. */
+extern "C" int svnet_v2s_cat_sum_fwd_f32(const float* v, const float* w_eff, const float* pre, int64_t pre_cols, int64_t M, int64_t C,
+                                         int64_t Jn, float* out, int64_t out_ld, double* pre_sum, int64_t rows_per_cloud, void* stream) {
+    SVNET_REQUIRE(pre && out && pre_cols > 0 && pre_sum, SVNET_E_ARG, "svnet_v2s_cat_sum_fwd_f32: bad arguments");
+    return v2s_fwd_launch(v, w_eff, M, C, Jn, out + pre_cols, out_ld, nullptr, pre, pre_cols, stream, pre_sum, rows_per_cloud);
 }
 
 extern "C" int svnet_v2s_bwd_ld_f32(const float* v, const float* w_eff, const float* ds, int64_t ds_ld, const float* dz_in, int64_t M,

@@ -346,6 +346,9 @@ class SVBlock(nn.Module):
         if not (self._v2s_cat_fusable(s, v) and s.dim() >= 3 and s.shape[-1] >= 128 and self.gate[0].out_features <= 256
                 and self.gate[2].out_features <= 256):
             return None
+        if config.FUSE_CAT_MEAN:      # the gate MLP inside the op, fed by column sums the concatenation kernel forms from its own copy of s
+            return _ops.V2SCat.apply(s, v, lin.weight, lin.scale if lin.bw else None, self.training, s.shape[0], self.gate[0].weight,
+                                     self.gate[2].weight)
         cat, s_mean = _ops.V2SCat.apply(s, v, lin.weight, lin.scale if lin.bw else None, self.training, s.shape[0])
         return cat, _ops.GateMLP.apply(s_mean, self.gate[0].weight, self.gate[2].weight)
 

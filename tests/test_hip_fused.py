@@ -667,3 +667,46 @@ def test_models_give_the_same_bits_with_and_without_the_block_tail(model_name, B
     for n, g_ in res[True][2].items():
         ref = res[False][2][n]
         assert float(np.abs(g_ - ref).max()) <= 1e-4 * float(np.abs(ref).max()) + 1e-5 * gmax, n
+
+
+# ----------------------------------------------------------------------------- conv5's concatenation with the gate's mean inside
+
+@pytest.mark.parametrize("cfg", [(4, 256, 256, 83, True), (2, 1024, 256, 83, True), (3, 64, 200, 40, False), (2, 48, 256, 83, True)],
+                         ids=["n256", "n1024", "fp_w200", "n48_fallback"])
+def test_cat_with_the_gate_mean_inside_equals_cat_pool_gate(cfg, hip_device):
+    """_ops.V2SCat with the block's gate MLP (config.FUSE_CAT_MEAN; svnet_v2s_cat_sum_fwd_f32: per-cloud fp64 column sums of s from the
+    concatenation kernel's own copy, the MLP started from them) against V2SCat + the pooling pass + _ops.GateMLP (sv_layers.py:179-188):
+    the concatenation bit for bit, the gate to 1e-6, every gradient to 2e-5 of its largest element.  N = 48 is outside the summing
+    kernel's shapes (whole 32-row blocks per cloud): the op then pools by its own pass."""
+    from svnet_amd import _ops
+    B, N, Cs, Cv, binary = cfg
+    H, Ov = 85, 170
+    g = torch.Generator().manual_seed(3 + N + Cs)
+    s0, v0 = torch.randn(B, N, Cs, generator=g), torch.randn(B, N, 3, Cv, generator=g)
+    Wz0 = torch.randn(3, Cv, generator=g)
+    scz0 = (torch.rand(1, 3, generator=g) + 0.5) if binary else None
+    W00, W20 = torch.randn(H, Cs, generator=g) * 0.1, torch.randn(Ov, H, generator=g) * 0.3
+    wc, wg = torch.randn(B, N, Cs + 3 * Cv, generator=g).to(hip_device), torch.randn(B, Ov, generator=g).to(hip_device)
+    res = {}
+    for fused in (True, False):
+        s, v, Wz, W0, W2 = (t.clone().to(hip_device).requires_grad_(True) for t in (s0, v0, Wz0, W00, W20))
+        scz = None if scz0 is None else scz0.clone().to(hip_device).requires_grad_(True)
+        if fused:
+            cat, gate = _ops.V2SCat.apply(s, v, Wz, scz, True, B, W0, W2)
+        else:
+            cat, s_mean = _ops.V2SCat.apply(s, v, Wz, scz, True, B)
+            gate = _ops.GateMLP.apply(s_mean, W0, W2)
+        ((cat * wc).sum() + (gate * wg).sum()).backward()
+        torch.cuda.synchronize()
+        res[fused] = dict(cat=cat.detach().cpu(), gate=gate.detach().cpu(), ds=s.grad.cpu(), dv=v.grad.cpu(), dWz=Wz.grad.cpu(), dW0=W0.grad.cpu(),
+                          dW2=W2.grad.cpu(), dscz=None if scz is None else scz.grad.cpu())
+    assert torch.equal(res[True]["cat"], res[False]["cat"])
+    assert float((res[True]["gate"] - res[False]["gate"]).abs().max()) <= 1e-6
+    ref_gate = torch.sigmoid(torch.relu(s0.mean(1) @ W00.t()) @ W20.t())
+    assert float((res[True]["gate"] - ref_gate).abs().max()) <= 1e-5
+    for n in ("ds", "dv", "dWz", "dW0", "dW2", "dscz"):
+        a_, b_ = res[True][n], res[False][n]
+        if b_ is None:
+            assert a_ is None
+            continue
+        assert float((a_ - b_).abs().max()) <= 2e-5 * max(float(b_.abs().max()), 1e-6), n
