@@ -7,10 +7,13 @@
 // s_v [P,510] nor the gradient of s_v is needed by anything else (sv_dgcnn_cls.py:69-74 pools the feature at once), so here
 //   forward : ONE read of the product; v5 and s_v live in registers; packed arg-max keys + ordered partial sums per (cloud, row chunk);
 //   backward: ONE read of the product, v5 / z recomputed, the pooled gradient (point == arg-max ? g_max : 0) + g_mean / N formed on the
-//             fly, Vector2Scalar's backward in registers, VectorBN's batch sums and the gate's gradient accumulated, dL/dv5 written once
-//             for the (unchanged) VectorBN apply pass.
+//             fly, Vector2Scalar's backward in registers, VectorBN's batch sums and the gate's gradient accumulated; a second pass
+//             (APPLY) makes the same recomputation and applies VectorBN's backward with the totals of those sums - dL/dv written once,
+//             dL/dv5 never (svnet_vtail_bwd_apply_f32; with g5 given, the first pass stores it for svnet_vbn_bwd_apply_f32 instead).
 // A wave owns a point: lane g holds channels g, g + 64, g + 128 (C <= 192) of the three axes; the 3 x 3 frame z is nine wave sums.
-// Same arithmetic, in the same order, as vbn_fwd_kernel (norm.hip) and v2s_fwd_kernel (v2s.hip): the pooled maxima equal the layer-wise chain's.
+// The formulas are those of vbn_fwd_kernel (norm.hip) and v2s_fwd_kernel (v2s.hip) with ONE division per channel (rr / n * gate, applied
+// to the three axes) and other contractions: values agree with the layer-wise chain to rounding (2e-5 of a tensor's largest element,
+// arg-max equal but for near-ties: tests/test_hip_fused.py), not bit for bit.
 #include "common.h"
 
 namespace {
