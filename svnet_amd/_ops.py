@@ -1709,6 +1709,25 @@ class GateMLPRows(torch.autograd.Function):
         return ds, dW0, dW2
 
 
+class _UnitGrad:
+    """One cached scalar 1.0 per device: a train step seeds its backward with it (`torch.autograd.backward(loss, UNIT_GRAD.get(dev))`)
+    instead of `loss.backward()`'s fresh ones_like, and SmoothCE.backward recognises it BY IDENTITY - the fill kernel and the
+    multiplication by one were two launches (~10 us) on the critical path between the forward and the backward."""
+
+    def __init__(self):
+        self.t = {}
+
+    def get(self, dev):
+        dev = torch.device(dev)
+        key = (dev.type, dev.index if dev.index is not None else (torch.cuda.current_device() if dev.type == "cuda" else 0))
+        if key not in self.t:
+            self.t[key] = torch.ones((), dtype=torch.float32, device=dev)
+        return self.t[key]
+
+
+UNIT_GRAD = _UnitGrad()
+
+
 class SmoothCE(torch.autograd.Function):
     """Label-smoothed cross entropy, mean over rows (utils.py:33-50 cal_loss)."""
 
@@ -1728,6 +1747,8 @@ class SmoothCE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dlog,) = ctx.saved_tensors
+        if g is UNIT_GRAD.get(dlog.device):      # the step's own seed (train.TrainStep: a cached 1.0): dL/dlogits is dlog itself
+            return dlog, None, None
         return dlog * g, None, None
 
 

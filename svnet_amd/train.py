@@ -73,7 +73,10 @@ class TrainStep:
             loss = self.loss_fn(self.model(*self.inputs), self.target)
             # nothing reads a parameter gradient before pack() (checked: _deferral_is_safe): see _ops._Deferred
             _ops.DEFERRED.active = bool(config.DEFER_WGRAD) and self._deferral_is_safe()
-            loss.backward()
+            if loss.dim() == 0 and loss.is_cuda and loss.dtype == torch.float32:
+                torch.autograd.backward(loss, _ops.UNIT_GRAD.get(loss.device))      # (a cached 1.0: no fill, no multiplication by one)
+            else:
+                loss.backward()
             _ops.DEFERRED.join(self.bucket.flat.device)
             self.bucket.pack()                              # one batched copy of all gradients into the flat bucket
         finally:
