@@ -52,6 +52,27 @@ def test_argument_errors_do_not_need_a_gpu():
     assert b"null" in L.svnet_last_error()
 
 
+def test_shape_queries_of_the_fused_launches_answer_without_a_gpu():
+    """The host-side "is this shape taken" queries the Python layer asks before it chooses a fused launch (round 5: the k-NN table
+    prepared by the previous level's apply pass, the one-launch block tail, the concatenation with the gate's sums): pure host
+    functions - same answers here as on the GPU box, and the refusals the GPU tests rely on."""
+    from svnet_amd import _lib
+    L = _lib.lib()
+    # k-NN table from the apply pass: whole 32-point tiles per cloud, 8 <= C <= 384, channel-major table (default build: always)
+    assert L.svnet_knn_table_fusable(32, 1024, 62) == 1 and L.svnet_knn_table_fusable(32, 2048, 127) == 1
+    assert L.svnet_knn_table_fusable(2, 100, 62) == 0 and L.svnet_knn_table_fusable(2, 1024, 4) == 0 and L.svnet_knn_table_fusable(0, 1024, 62) == 0
+    assert L.svnet_knn_table_fusable(2, 1024, 385) == 0 and L.svnet_knn_table_fusable(2, 8192, 62) == 0
+    # block tail: P a whole number of clouds of N % 32 == 0 points, widths <= 256
+    assert L.svnet_block_tail_supported(32768, 1024, 128, 42, 0) == 1 and L.svnet_block_tail_supported(32768, 1024, 128, 42, 1) == 1
+    assert L.svnet_block_tail_supported(200, 100, 32, 10, 0) == 0 and L.svnet_block_tail_supported(1000, 1024, 32, 10, 0) == 0
+    assert L.svnet_block_tail_supported(2048, 1024, 300, 10, 0) == 0 and L.svnet_block_tail_supported(2048, 1024, 2, 1, 1) == 0      # (C = 5 < 8: no table)
+    assert L.svnet_block_tail_supported(2048, 1024, 2, 1, 0) == 1
+    # concatenation + per-cloud sums: 24 < C <= 192, pre_cols <= 8 lanes' worth, whole clouds of whole row blocks
+    assert L.svnet_v2s_cat_sum_supported(32768, 83, 256, 1024) == 1 and L.svnet_v2s_cat_sum_supported(65536, 80, 256, 2048) == 1
+    assert L.svnet_v2s_cat_sum_supported(96, 83, 256, 48) == 0 and L.svnet_v2s_cat_sum_supported(32768, 10, 64, 1024) == 0
+    assert L.svnet_v2s_cat_sum_supported(32768, 83, 300, 1024) == 0 and L.svnet_v2s_cat_sum_supported(32768, 340, 512, 1024) == 0
+
+
 def test_product_path_has_no_cpu_fallback():
     from svnet_amd.models.utils.sv_util import knn, svpool
     from svnet_amd.models.sv_layers import Linear
