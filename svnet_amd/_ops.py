@@ -490,6 +490,7 @@ def begin_step(dev, planes_external=False, arena=None):
 
 def end_step():
     global ARENA, _FUSED_COLSUMS, _FUSED_VSTATS
+    knn_table_ahead.table = None                          # (a prepared k-NN table nobody asked for is not held across steps)
     _FUSED_VSTATS = None
     _FUSED_COLSUMS = None                                 # (the producer's [M, O] output and its arena slice are not held across steps)
     ARENA.end()
