@@ -2044,7 +2044,8 @@ class EdgeBlock(torch.autograd.Function):
         rev_src = torch.empty((E,), dtype=torch.int32, device=dev)
         # reverse lists longer than GATHER_CHUNK entries are summed in pieces (feature-space graphs have hubs: a wave per whole list
         # made the gather as slow as its longest list)
-        GATHER_CHUNK = int(config.GATHER_CHUNK)
+        # (the list lengths scale with k - their mean IS k: k = 40, part-seg, 15.86 -> 15.81 ms with 256 entries per wave, profiles/r05_ab_partseg_switches.log)
+        GATHER_CHUNK = int(config.GATHER_CHUNK) * max(1, (k + 19) // 20)
         ovf_items = torch.empty((2 * (2 * E // GATHER_CHUNK + 1),), dtype=torch.int32, device=dev) if GATHER_CHUNK > 0 else None
         if ovf_items is None:
             ovf_count = None
